@@ -1,0 +1,556 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+A numpy (fp64) restatement of the reference algorithm for the hot path of
+SSTDV-Project/python-fluid-simulation: the CG pressure / viscosity solvers.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import this file, and only as the checker.
+
+Parity status: PINNED against tests/golden/*.npz, which were produced by
+executing the reference's own source files under CPython with container-only
+array/launch plumbing (tests/golden/make_goldens.py).
+The reference ships no tests or fixtures of its own for this path.  Not pinned
+against cupy/numba-CUDA execution itself (unavailable here): FMA contraction
+and cp.sum reduction order may differ from this file at the 1e-16 level.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference repo root).  Array conventions: SURVEY.md section 8.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F64 = np.float64
+
+
+# =============================================================================
+# solid fractions
+# =============================================================================
+def edge_in_fraction(lval, rval):
+    """solver/SolidFractionCommon.py:4-16 (vectorised; returns fp64)."""
+    lval = np.asarray(lval, F64)
+    rval = np.asarray(rval, F64)
+    l_in = lval < 0
+    r_in = rval < 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        diff = -np.abs(lval - rval)
+        out = np.where(l_in & r_in, 1.0,
+                       np.where(~l_in & ~r_in, 0.0,
+                                np.where(l_in & ~r_in, lval / diff, rval / diff)))
+    return out
+
+
+def tri_in_fraction(v0, v1, v2):
+    """solver/SolidFractionCommon.py:18-50, branch for branch.
+
+    As written in the reference this is 1.0 iff all three vertices are < 0 and
+    0.0 otherwise: with two vertices inside, lines 31-39 pick the
+    two *inside* vertices (edge fraction 1 -> 1-1 = 0); with one inside, lines
+    40-48 pick the two *outside* vertices (edge fraction 0).  The general
+    selection logic is kept so the restatement does not depend on that reading.
+    """
+    v = np.stack(np.broadcast_arrays(np.asarray(v0, F64), np.asarray(v1, F64), np.asarray(v2, F64)), axis=-1)
+    vin = v < 0
+    cnt = vin.sum(axis=-1)
+    v0_in, v1_in = vin[..., 0], vin[..., 1]
+    # in_count == 2 (:31-39)
+    out_v = np.where(v0_in, np.where(v1_in, 2, 1), 0)
+    a = np.take_along_axis(v, ((out_v + 1) % 3)[..., None], axis=-1)[..., 0]
+    b = np.take_along_axis(v, ((out_v + 2) % 3)[..., None], axis=-1)[..., 0]
+    two = 1.0 - edge_in_fraction(a, b)
+    # in_count == 1 (:40-48)
+    in_v = np.where(~v0_in, np.where(~v1_in, 2, 1), 0)
+    a = np.take_along_axis(v, ((in_v + 1) % 3)[..., None], axis=-1)[..., 0]
+    b = np.take_along_axis(v, ((in_v + 2) % 3)[..., None], axis=-1)[..., 0]
+    one = edge_in_fraction(a, b)
+    return np.where(cnt == 3, 1.0, np.where(cnt == 2, two, np.where(cnt == 1, one, 0.0)))
+
+
+def face_in_fraction(bl, br, tl, tr):
+    """solver/SolidFractionCommon.py:52-60."""
+    bl, br, tl, tr = (np.asarray(a, F64) for a in (bl, br, tl, tr))
+    ce = 0.25 * (bl + br + tl + tr)
+    return 0.25 * (tri_in_fraction(bl, br, ce) + tri_in_fraction(br, tr, ce)
+                   + tri_in_fraction(tr, tl, ce) + tri_in_fraction(tl, bl, ce))
+
+
+def compute_solid_frac3d(gres, sphi, wx, wy, wz):
+    """solver/SolidFraction3D.py:6-32.  Writes w*[0:N] only; the upper faces
+    w*[N] are never written (lines 21,23,25 are commented out) -> stay as given."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    s = np.asarray(sphi, F64)
+    n = lambda ox, oy, oz: s[ox:ox + 2 * Nx:2, oy:oy + 2 * Ny:2, oz:oz + 2 * Nz:2]  # noqa: E731
+    blb, brb, tlb, trb = n(0, 0, 0), n(2, 0, 0), n(0, 2, 0), n(2, 2, 0)
+    blf, brf, tlf = n(0, 0, 2), n(2, 0, 2), n(0, 2, 2)
+    wx[:Nx, :Ny, :Nz] = 1.0 - face_in_fraction(tlb, blb, tlf, blf)   # :22
+    wy[:Nx, :Ny, :Nz] = 1.0 - face_in_fraction(brb, blb, brf, blf)   # :24
+    wz[:Nx, :Ny, :Nz] = 1.0 - face_in_fraction(trb, tlb, brb, blb)   # :26
+
+
+def compute_solid_frac2d(gres, sphi, wx, wy):
+    """solver/SolidFraction2D.py:6-26: for x<Nx-1, y<Ny-1 writes BOTH faces of the
+    cell with true linear edge fractions.  Written in launch order semantics: a
+    face shared by two cells is written twice with the same value."""
+    Nx, Ny = (int(g) for g in gres)
+    s = np.asarray(sphi, F64)
+    n = lambda ox, oy: s[ox:ox + 2 * (Nx - 1):2, oy:oy + 2 * (Ny - 1):2]  # noqa: E731
+    bl, br, tl, tr = n(0, 0), n(2, 0), n(0, 2), n(2, 2)
+    wx[1:Nx, 0:Ny - 1] = 1.0 - edge_in_fraction(tr, br)     # :17
+    wx[0:Nx - 1, 0:Ny - 1] = 1.0 - edge_in_fraction(tl, bl)  # :18
+    wy[0:Nx - 1, 1:Ny] = 1.0 - edge_in_fraction(tr, tl)     # :19
+    wy[0:Nx - 1, 0:Ny - 1] = 1.0 - edge_in_fraction(br, bl)  # :20
+    # overlap check: the value written to wx[x+1,y] by cell (x,y) equals the one
+    # written to wx[x+1,y] by cell (x+1,y) as its own left face (same two nodes).
+
+
+# =============================================================================
+# pressure, 3D
+# =============================================================================
+def _theta(phi, nphi):
+    """min(1, max(0.01, phi/(phi-nphi))) -- solver/PressureCGSolver3D.py:75."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.minimum(1.0, np.maximum(0.01, phi / (phi - nphi)))
+
+
+def pressure_rhs3d(cell_size, gres, vx, vy, vz, sphi, sv, lphi, b, wx, wy, wz):
+    """solver/PressureCGSolver3D.py:6-50 (initialize_solver_kernel)."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    cs = [float(c) for c in cell_size]
+    I = (slice(1, Nx - 1), slice(1, Ny - 1), slice(1, Nz - 1))
+    sv = np.asarray(sv, F64)
+
+    def dgrid(ox, oy, oz, comp):   # sv[2x+ox, 2y+oy, 2z+oz, comp] over interior cells
+        return sv[2 + ox:2 * (Nx - 1) + ox:2, 2 + oy:2 * (Ny - 1) + oy:2, 2 + oz:2 * (Nz - 1) + oz:2, comp]
+
+    def sh(a, dx, dy, dz):
+        return np.asarray(a)[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy, 1 + dz:Nz - 1 + dz].astype(F64)
+
+    bv = np.zeros((Nx - 2, Ny - 2, Nz - 2))
+    terms = [  # (w, v, sign, cs, sv sample)  in the reference's order :20-47
+        (sh(wx, 1, 0, 0), sh(vx, 1, 0, 0), +1, cs[0], dgrid(2, 1, 1, 0)),
+        (sh(wx, 0, 0, 0), sh(vx, 0, 0, 0), -1, cs[0], dgrid(0, 1, 1, 0)),
+        (sh(wy, 0, 1, 0), sh(vy, 0, 1, 0), +1, cs[1], dgrid(1, 2, 1, 1)),
+        (sh(wy, 0, 0, 0), sh(vy, 0, 0, 0), -1, cs[1], dgrid(1, 0, 1, 1)),
+        (sh(wz, 0, 0, 1), sh(vz, 0, 0, 1), +1, cs[2], dgrid(1, 1, 2, 2)),
+        (sh(wz, 0, 0, 0), sh(vz, 0, 0, 0), -1, cs[2], dgrid(1, 1, 0, 2)),
+    ]
+    for w, v, sgn, c, s in terms:
+        bv = bv + sgn * (w * v / c)
+        bv = bv - sgn * np.where(w < 1, w * s / c, 0.0)
+    fluid = np.asarray(lphi, F64)[I] < 0
+    b[I] = np.where(fluid, bv, 0.0)
+
+
+def pressure_apply3d(gres, v, out, wx, wy, wz, lphi):
+    """solver/PressureCGSolver3D.py:52-130 (matvecmul_kernel).  Boundary cells of
+    `out` are not written (:55-57); non-fluid interior cells get 0 (:60-63)."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    I = (slice(1, Nx - 1), slice(1, Ny - 1), slice(1, Nz - 1))
+
+    def sh(a, dx, dy, dz):
+        return np.asarray(a, F64)[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy, 1 + dz:Nz - 1 + dz]
+
+    phi = sh(lphi, 0, 0, 0)
+    val = np.zeros_like(phi)
+    diag = np.zeros_like(phi)
+    nbrs = [  # (neighbour offset, face weight) in the reference's order: +x -x +y -y +z -z
+        ((1, 0, 0), sh(wx, 1, 0, 0)), ((-1, 0, 0), sh(wx, 0, 0, 0)),
+        ((0, 1, 0), sh(wy, 0, 1, 0)), ((0, -1, 0), sh(wy, 0, 0, 0)),
+        ((0, 0, 1), sh(wz, 0, 0, 1)), ((0, 0, -1), sh(wz, 0, 0, 0)),
+    ]
+    for off, w in nbrs:
+        nphi = sh(lphi, *off)
+        nf = nphi < 0
+        val = val - np.where(nf, w * sh(v, *off), 0.0)
+        diag = diag + np.where(nf, w, w / _theta(phi, nphi))
+    val = val + diag * sh(v, 0, 0, 0)
+    out[I] = np.where(phi < 0, val, 0.0)
+
+
+def pressure_update3d(gres, cell_size, vx, vy, vz, pv, wx, wy, wz, sv, lphi):
+    """solver/PressureCGSolver3D.py:132-153 (apply_pressure_kernel): x,y,z in
+    [1, N-1]; in-place, result cast to the velocity dtype (Q11)."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    cs = [float(c) for c in cell_size]
+    lphi = np.asarray(lphi, F64)
+    pv = np.asarray(pv, F64)
+    sv = np.asarray(sv, F64)
+    C = (slice(1, Nx), slice(1, Ny), slice(1, Nz))
+    for axis, (vel, w, c) in enumerate(((vx, wx, cs[0]), (vy, wy, cs[1]), (vz, wz, cs[2]))):
+        M = tuple(slice(1 - (axis == a), (Nx, Ny, Nz)[a] - (axis == a)) for a in range(3))
+        pc, pm = lphi[C], lphi[M]
+        act = (pc < 0) | (pm < 0)
+        theta = np.minimum(1.0, np.maximum(0.01, edge_in_fraction(pc, pm)))
+        # sv sample: (2x,2y+1,2z+1,0) / (2x+1,2y,2z+1,1) / (2x+1,2y+1,2z,2)
+        sx = slice(2 + (axis != 0), 2 * Nx + (axis != 0), 2)
+        sy = slice(2 + (axis != 1), 2 * Ny + (axis != 1), 2)
+        sz = slice(2 + (axis != 2), 2 * Nz + (axis != 2), 2)
+        svs = sv[sx, sy, sz, axis]
+        wv = np.asarray(w, F64)[C]
+        old = np.asarray(vel)[C].astype(F64)
+        new = old + (pv[C] - pv[M]) * c / theta
+        new = wv * new + (1 - wv) * svs
+        vel[C] = np.where(act, new, old).astype(vel.dtype)
+
+
+def cg(apply, b, x, d, r, q, tol, max_iter, history=None, raise_on_fail=True, dot=None):
+    """The CG loop shared by all solvers: solver/PressureCGSolver3D.py:198-223
+    (and solver/ViscosityCGSolver3D.py:575-612, solver/PressureCGSolver2D.py:159-177).
+
+    `x,d,r,q,b` are arrays or tuples of arrays (viscosity: 3 components).  Plain
+    un-preconditioned CG, ABSOLUTE tolerance delta < tol**2 tested after the x/r
+    update and before the direction update (Q1,Q2); A.x0 is evaluated even when
+    x0 = 0 (Q5).  Returns (iterations, delta, alpha, beta).
+    history receives [delta0, dq1, delta1, dq2, delta2, ...].
+    """
+    tup = isinstance(x, (tuple, list))
+    X, D, R, Q, B = ((a if tup else (a,)) for a in (x, d, r, q, b))
+    if dot is None:
+        def dot(A_, B_):
+            s = None
+            for a_, b_ in zip(A_, B_):
+                t = np.sum(a_ * b_)
+                s = t if s is None else s + t
+            return float(s)
+    apply(X, Q)
+    for d_, b_, q_, r_ in zip(D, B, Q, R):
+        d_[...] = b_ - q_
+        r_[...] = d_
+    delta = dot(R, R)
+    if history is not None:
+        history.append(delta)
+    alpha = beta = 0.0
+    it = 0
+    if not delta < tol ** 2:
+        converged = False
+        for it in range(1, int(max_iter) + 1):
+            apply(D, Q)
+            dq = dot(D, Q)
+            alpha = delta / dq
+            for x_, d_, r_, q_ in zip(X, D, R, Q):
+                x_ += alpha * d_
+                r_ -= alpha * q_
+            old = delta
+            delta = dot(R, R)
+            if history is not None:
+                history.extend((dq, delta))
+            if delta < tol ** 2:
+                converged = True
+                break
+            beta = delta / old
+            for d_, r_ in zip(D, R):
+                d_[...] = r_ + beta * d_
+        if not converged and raise_on_fail:
+            raise ValueError("Failed to converge!")
+    return it, delta, alpha, beta
+
+
+class PressureCGSolver3D:
+    """solver/PressureCGSolver3D.py:173-226 on numpy arrays."""
+
+    def __init__(self, gres, bound_size):
+        self.gres = tuple(int(g) for g in gres)
+        self.cell_size = np.broadcast_to(np.asarray(bound_size, F64), (3,)) / np.asarray(self.gres, F64)
+        Nx, Ny, Nz = self.gres
+        self.d, self.r, self.q, self.b, self.x = (np.zeros(self.gres) for _ in range(5))
+        self.wx = np.zeros((Nx + 1, Ny, Nz))
+        self.wy = np.zeros((Nx, Ny + 1, Nz))
+        self.wz = np.zeros((Nx, Ny, Nz + 1))
+        self.max_iter = Nx * Ny * Nz
+        self.history = []
+        self.iterations = 0
+
+    def solve(self, vx, vy, vz, sphi, sv, lphi, wx=None, wy=None, wz=None, tol=1e-3, max_iter=None,
+              raise_on_fail=True):
+        if wx is None or wy is None or wz is None:
+            compute_solid_frac3d(self.gres, sphi, self.wx, self.wy, self.wz)
+            wx, wy, wz = self.wx, self.wy, self.wz
+        self.x *= 0.0
+        pressure_rhs3d(self.cell_size, self.gres, vx, vy, vz, sphi, sv, lphi, self.b, wx, wy, wz)
+        self.history = []
+        ap = lambda V, O: pressure_apply3d(self.gres, V[0], O[0], wx, wy, wz, lphi)  # noqa: E731
+        self.iterations, self.delta, self.alpha, self.beta = cg(
+            ap, self.b, self.x, self.d, self.r, self.q, tol,
+            self.max_iter if max_iter is None else max_iter, self.history, raise_on_fail)
+        pressure_update3d(self.gres, self.cell_size, vx, vy, vz, self.x, wx, wy, wz, sv, lphi)
+
+
+# =============================================================================
+# pressure, 2D (config 1)
+# =============================================================================
+def pressure_rhs2d(cell_size, gres, vx, vy, sphi, sv, lphi, b, wx, wy):
+    """solver/PressureCGSolver2D.py:6-44."""
+    Nx, Ny = (int(g) for g in gres)
+    cs = [float(c) for c in cell_size]
+    sv = np.asarray(sv, F64)
+
+    def sh(a, dx, dy):
+        return np.asarray(a)[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy].astype(F64)
+
+    def dgrid(ox, oy, comp):
+        return sv[2 + ox:2 * (Nx - 1) + ox:2, 2 + oy:2 * (Ny - 1) + oy:2, comp]
+
+    bv = np.zeros((Nx - 2, Ny - 2))
+    for w, v, sgn, c, s in [
+        (sh(wx, 1, 0), sh(vx, 1, 0), +1, cs[0], dgrid(2, 1, 0)),
+        (sh(wx, 0, 0), sh(vx, 0, 0), -1, cs[0], dgrid(0, 1, 0)),
+        (sh(wy, 0, 1), sh(vy, 0, 1), +1, cs[1], dgrid(1, 2, 1)),
+        (sh(wy, 0, 0), sh(vy, 0, 0), -1, cs[1], dgrid(1, 0, 1)),
+    ]:
+        bv = bv + sgn * (w * v / c)
+        bv = bv - sgn * np.where(w < 1, w * s / c, 0.0)
+    I = (slice(1, Nx - 1), slice(1, Ny - 1))
+    b[I] = np.where(np.asarray(lphi, F64)[I] < 0, bv, 0.0)
+
+
+def pressure_apply2d(gres, v, out, wx, wy, lphi):
+    """solver/PressureCGSolver2D.py:46-100."""
+    Nx, Ny = (int(g) for g in gres)
+
+    def sh(a, dx, dy):
+        return np.asarray(a, F64)[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy]
+
+    phi = sh(lphi, 0, 0)
+    val = np.zeros_like(phi)
+    diag = np.zeros_like(phi)
+    for off, w in [((1, 0), sh(wx, 1, 0)), ((-1, 0), sh(wx, 0, 0)),
+                   ((0, 1), sh(wy, 0, 1)), ((0, -1), sh(wy, 0, 0))]:
+        nphi = sh(lphi, *off)
+        nf = nphi < 0
+        val = val - np.where(nf, w * sh(v, *off), 0.0)
+        diag = diag + np.where(nf, w, w / _theta(phi, nphi))
+    val = val + diag * sh(v, 0, 0)
+    out[1:Nx - 1, 1:Ny - 1] = np.where(phi < 0, val, 0.0)
+
+
+def pressure_update2d(gres, cell_size, vx, vy, pv, wx, wy, sv, lphi):
+    """solver/PressureCGSolver2D.py:102-120."""
+    Nx, Ny = (int(g) for g in gres)
+    cs = [float(c) for c in cell_size]
+    lphi = np.asarray(lphi, F64)
+    pv = np.asarray(pv, F64)
+    sv = np.asarray(sv, F64)
+    C = (slice(1, Nx), slice(1, Ny))
+    for axis, (vel, w, c) in enumerate(((vx, wx, cs[0]), (vy, wy, cs[1]))):
+        M = tuple(slice(1 - (axis == a), (Nx, Ny)[a] - (axis == a)) for a in range(2))
+        pc, pm = lphi[C], lphi[M]
+        act = (pc < 0) | (pm < 0)
+        theta = np.minimum(1.0, np.maximum(0.01, edge_in_fraction(pc, pm)))
+        sx = slice(2 + (axis != 0), 2 * Nx + (axis != 0), 2)
+        sy = slice(2 + (axis != 1), 2 * Ny + (axis != 1), 2)
+        svs = sv[sx, sy, axis]
+        wv = np.asarray(w, F64)[C]
+        old = np.asarray(vel)[C].astype(F64)
+        new = old + (pv[C] - pv[M]) * c / theta
+        new = wv * new + (1 - wv) * svs
+        vel[C] = np.where(act, new, old).astype(vel.dtype)
+
+
+class PressureCGSolver2D:
+    """solver/PressureCGSolver2D.py:140-179; no error on non-convergence (Q3)."""
+
+    def __init__(self, gres, bound_size):
+        self.gres = tuple(int(g) for g in gres)
+        self.cell_size = np.broadcast_to(np.asarray(bound_size, F64), (2,)) / np.asarray(self.gres, F64)
+        Nx, Ny = self.gres
+        self.d, self.r, self.q, self.b, self.x = (np.zeros(self.gres) for _ in range(5))
+        self.wx = np.zeros((Nx + 1, Ny))
+        self.wy = np.zeros((Nx, Ny + 1))
+        self.max_iter = Nx * Ny
+        self.history = []
+        self.iterations = 0
+
+    def solve(self, vx, vy, sphi, sv, lphi, wx=None, wy=None, tol=1e-3):
+        if wx is None or wy is None:
+            compute_solid_frac2d(self.gres, sphi, self.wx, self.wy)
+            wx, wy = self.wx, self.wy
+        self.x *= 0.0
+        pressure_rhs2d(self.cell_size, self.gres, vx, vy, sphi, sv, lphi, self.b, wx, wy)
+        self.history = []
+        ap = lambda V, O: pressure_apply2d(self.gres, V[0], O[0], wx, wy, lphi)  # noqa: E731
+        self.iterations, self.delta, self.alpha, self.beta = cg(
+            ap, self.b, self.x, self.d, self.r, self.q, tol, self.max_iter, self.history,
+            raise_on_fail=False)
+        pressure_update2d(self.gres, self.cell_size, vx, vy, self.x, wx, wy, sv, lphi)
+
+
+# =============================================================================
+# viscosity, 3D
+# =============================================================================
+# Tap tables of the three operator rows (each entry was
+# re-read against solver/ViscosityCGSolver3D.py:248-456).  A row is described
+# relative to its own face: D = doubled-grid index of the face,
+#   u: D=(2x,2y+1,2z+1)   v: D=(2x+1,2y,2z+1)   w: D=(2x+1,2y+1,2z)
+# vol samples: c=D, R/L = D -/+ x, T/B = D -/+ y, F/K = D -/+ z.
+# tap = (factor, vol sample, sign in matvec, component, (dx,dy,dz) into that
+#        component's array, mask offset relative to D)
+_VOL_OFF = {"c": (0, 0, 0), "R": (1, 0, 0), "L": (-1, 0, 0), "T": (0, 1, 0), "B": (0, -1, 0),
+            "F": (0, 0, 1), "K": (0, 0, -1)}
+VISC_ROWS = {
+    0: dict(D0=(0, 1, 1), diag=(2, 2, 1, 1, 1, 1), taps=[
+        (2, "R", -1, 0, (1, 0, 0), (2, 0, 0)), (2, "L", -1, 0, (-1, 0, 0), (-2, 0, 0)),      # :272-276
+        (1, "T", -1, 0, (0, 1, 0), (0, 2, 0)), (1, "B", -1, 0, (0, -1, 0), (0, -2, 0)),      # :278-282
+        (1, "F", -1, 0, (0, 0, 1), (0, 0, 2)), (1, "K", -1, 0, (0, 0, -1), (0, 0, -2)),      # :284-288
+        (1, "T", -1, 1, (0, 1, 0), (1, 1, 0)), (1, "T", +1, 1, (-1, 1, 0), (-1, 1, 0)),      # :291-295
+        (1, "B", +1, 1, (0, 0, 0), (1, -1, 0)), (1, "B", -1, 1, (-1, 0, 0), (-1, -1, 0)),    # :297-301
+        (1, "F", -1, 2, (0, 0, 1), (1, 0, 1)), (1, "F", +1, 2, (-1, 0, 1), (-1, 0, 1)),      # :304-308
+        (1, "K", +1, 2, (0, 0, 0), (1, 0, -1)), (1, "K", -1, 2, (-1, 0, 0), (-1, 0, -1)),    # :310-314
+    ]),
+    1: dict(D0=(1, 0, 1), diag=(1, 1, 2, 2, 1, 1), taps=[
+        (1, "R", -1, 1, (1, 0, 0), (2, 0, 0)), (1, "L", -1, 1, (-1, 0, 0), (-2, 0, 0)),      # :342-346
+        (2, "T", -1, 1, (0, 1, 0), (0, 2, 0)), (2, "B", -1, 1, (0, -1, 0), (0, -2, 0)),      # :348-352
+        (1, "F", -1, 1, (0, 0, 1), (0, 0, 2)), (1, "K", -1, 1, (0, 0, -1), (0, 0, -2)),      # :354-358
+        (1, "R", -1, 0, (1, 0, 0), (1, 1, 0)), (1, "R", +1, 0, (1, -1, 0), (1, -1, 0)),      # :361-365
+        (1, "L", +1, 0, (0, 0, 0), (-1, 1, 0)), (1, "L", -1, 0, (0, -1, 0), (-1, -1, 0)),    # :367-371
+        (1, "F", -1, 2, (0, 0, 1), (0, 1, 1)), (1, "F", +1, 2, (0, -1, 1), (0, -1, 1)),      # :374-378
+        (1, "K", +1, 2, (0, 0, 0), (0, 1, -1)), (1, "K", -1, 2, (0, -1, 0), (0, -1, -1)),    # :380-384
+    ]),
+    2: dict(D0=(1, 1, 0), diag=(1, 1, 1, 1, 2, 2), taps=[
+        (1, "R", -1, 2, (1, 0, 0), (2, 0, 0)), (1, "L", -1, 2, (-1, 0, 0), (-2, 0, 0)),      # :412-416
+        (1, "T", -1, 2, (0, 1, 0), (0, 2, 0)), (1, "B", -1, 2, (0, -1, 0), (0, -2, 0)),      # :418-422
+        (2, "F", -1, 2, (0, 0, 1), (0, 0, 2)), (2, "K", -1, 2, (0, 0, -1), (0, 0, -2)),      # :424-428
+        (1, "R", -1, 0, (1, 0, 0), (1, 0, 1)), (1, "R", +1, 0, (1, 0, -1), (1, 0, -1)),      # :431-435
+        (1, "L", +1, 0, (0, 0, 0), (-1, 0, 1)), (1, "L", -1, 0, (0, 0, -1), (-1, 0, -1)),    # :437-441
+        (1, "T", -1, 1, (0, 1, 0), (0, 1, 1)), (1, "T", +1, 1, (0, 1, -1), (0, 1, -1)),      # :444-448
+        (1, "B", +1, 1, (0, 0, 0), (0, -1, 1)), (1, "B", -1, 1, (0, 0, -1), (0, -1, -1)),    # :450-454
+    ]),
+}
+
+
+def _face_shape(gres, axis):
+    s = [int(g) for g in gres]
+    s[axis] += 1
+    return tuple(s)
+
+
+def _row_views(gres, axis):
+    """helpers that slice doubled-grid arrays / component arrays over the
+    interior faces (1 <= idx <= shape-2 on every axis) of row `axis`."""
+    shp = _face_shape(gres, axis)
+    cnt = tuple(s - 2 for s in shp)
+    D0 = VISC_ROWS[axis]["D0"]
+    base = tuple(2 * 1 + D0[a] for a in range(3))   # doubled index of interior face idx=1
+
+    def dg(G, off):
+        sl = tuple(slice(base[a] + off[a], base[a] + off[a] + 2 * cnt[a], 2) for a in range(3))
+        return G[sl]
+
+    def comp(A, off):
+        sl = tuple(slice(1 + off[a], 1 + off[a] + cnt[a]) for a in range(3))
+        return A[sl]
+
+    I = tuple(slice(1, 1 + cnt[a]) for a in range(3))
+    return dg, comp, I
+
+
+def visc_extrapolate3d(gres, num_iter, vx, vy, vz, sphi):
+    """solver/ViscosityCGSolver3D.py:8-39,472-502: `num_iter` Jacobi sweeps of the
+    6-neighbour average into invalid (sphi<0) interior faces."""
+    sphi = np.asarray(sphi, F64)
+    valids = [sphi[0::2, 1::2, 1::2] >= 0, sphi[1::2, 0::2, 1::2] >= 0, sphi[1::2, 1::2, 0::2] >= 0]
+    for _ in range(num_iter):
+        for v, valid in zip((vx, vy, vz), valids):
+            n = v.shape
+            I = (slice(1, n[0] - 1), slice(1, n[1] - 1), slice(1, n[2] - 1))
+            val = np.zeros(tuple(s - 2 for s in n))
+            count = np.zeros(val.shape, dtype=np.int64)
+            for off in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+                sl = tuple(slice(1 + o, s - 1 + o) for o, s in zip(off, n))
+                m = valid[sl]
+                val = val + np.where(m, v[sl], 0.0)
+                count = count + m
+            upd = (~valid[I]) & (count > 0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                newv = np.where(upd, val / count, v[I])
+            v[I] = newv          # Jacobi: neighbours read above are all old values
+            nv = valid.copy()
+            nv[I] = valid[I] | upd
+            valid[...] = nv
+
+
+def _visc_row(axis, gres, scale, mu, V, sphi, vol, rhs):
+    dg, comp, I = _row_views(gres, axis)
+    row = VISC_ROWS[axis]
+    vs = {k: dg(vol, o) for k, o in _VOL_OFF.items()}
+    own = comp(V[axis], (0, 0, 0))
+    solid = dg(sphi, (0, 0, 0)) < 0
+    if rhs:
+        val = own * vs["c"]                                            # :61
+    else:
+        fR, fL, fT, fB, fF, fK = row["diag"]
+        m = lambda f, a: a if f == 1 else f * a  # noqa: E731
+        diag = vs["c"] + scale * mu * (m(fR, vs["R"]) + m(fL, vs["L"]) + m(fT, vs["T"])
+                                       + m(fB, vs["B"]) + m(fF, vs["F"]) + m(fK, vs["K"]))   # :268
+        val = diag * own
+    for fac, vname, sgn, c, off, moff in row["taps"]:
+        k = (2 * scale * mu) if fac == 2 else (scale * mu)
+        term = k * vs[vname] * comp(V[c], off)
+        ms = dg(sphi, moff)
+        if rhs:      # Dirichlet side: neighbour face inside solid, opposite sign (:64-106)
+            val = val - sgn * np.where(ms < 0, term, 0.0)
+        else:
+            val = val + sgn * np.where(ms >= 0, term, 0.0)
+    return I, np.where(solid, 0.0, val)
+
+
+def visc_rhs3d(gres, scale, mu, vx, vy, vz, sphi, sv, vol, b_x, b_y, b_z):
+    """solver/ViscosityCGSolver3D.py:41-246,504-513.  `sv` is accepted and unused (Q12)."""
+    V = (np.asarray(vx, F64), np.asarray(vy, F64), np.asarray(vz, F64))
+    for axis, b in enumerate((b_x, b_y, b_z)):
+        I, val = _visc_row(axis, gres, scale, mu, V, np.asarray(sphi, F64), np.asarray(vol, F64), True)
+        b[I] = val
+
+
+def visc_apply3d(gres, scale, mu, vx, vy, vz, out_x, out_y, out_z, sphi, vol):
+    """solver/ViscosityCGSolver3D.py:248-456,515-524."""
+    V = (np.asarray(vx, F64), np.asarray(vy, F64), np.asarray(vz, F64))
+    for axis, o in enumerate((out_x, out_y, out_z)):
+        I, val = _visc_row(axis, gres, scale, mu, V, np.asarray(sphi, F64), np.asarray(vol, F64), False)
+        o[I] = val
+
+
+def visc_writeback3d(gres, vx, vy, vz, out_x, out_y, out_z, sphi, sv=None):
+    """solver/ViscosityCGSolver3D.py:458-470,526-530: x,y,z in [1,N-1]."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    sphi = np.asarray(sphi, F64)
+    C = (slice(1, Nx), slice(1, Ny), slice(1, Nz))
+    for axis, (v, o) in enumerate(((vx, out_x), (vy, out_y), (vz, out_z))):
+        sx = slice(2 + (axis != 0), 2 * Nx + (axis != 0), 2)
+        sy = slice(2 + (axis != 1), 2 * Ny + (axis != 1), 2)
+        sz = slice(2 + (axis != 2), 2 * Nz + (axis != 2), 2)
+        m = sphi[sx, sy, sz] >= 0
+        v[C] = np.where(m, np.asarray(o, F64)[C], v[C].astype(F64)).astype(v.dtype)
+
+
+class ViscosityCGSolver3D:
+    """solver/ViscosityCGSolver3D.py:532-613 on numpy arrays."""
+
+    def __init__(self, gres, bound_size):
+        self.gres = tuple(int(g) for g in gres)
+        self.cell_size = np.broadcast_to(np.asarray(bound_size, F64), (3,)) / np.asarray(self.gres, F64)
+        self.cell_vol = float(np.prod(self.cell_size))
+        self.vol = np.zeros(tuple(2 * g + 1 for g in self.gres))
+        for nm in "drqxb":
+            for a, c in enumerate("xyz"):
+                setattr(self, f"{nm}_{c}", np.zeros(_face_shape(self.gres, a)))
+        self.max_iter = int(np.prod(self.gres))
+        self.history = []
+        self.iterations = 0
+
+    def solve(self, dt, mu, rho, vx, vy, vz, sphi, sv, lphi, lvol, tol=1e-3, max_iter=None,
+              raise_on_fail=True):
+        scale = dt / self.cell_vol / rho                     # :567
+        self.vol[...] = np.asarray(lvol, F64) / (self.cell_vol * 0.125)   # :568
+        self.x_x[...] = vx
+        self.x_y[...] = vy
+        self.x_z[...] = vz
+        visc_extrapolate3d(self.gres, 3, self.x_x, self.x_y, self.x_z, sphi)
+        visc_rhs3d(self.gres, scale, mu, self.x_x, self.x_y, self.x_z, sphi, sv, self.vol,
+                   self.b_x, self.b_y, self.b_z)
+        self.history = []
+        ap = lambda V, O: visc_apply3d(self.gres, scale, mu, V[0], V[1], V[2], O[0], O[1], O[2], sphi, self.vol)  # noqa: E731
+        X = (self.x_x, self.x_y, self.x_z)
+        self.iterations, self.delta, self.alpha, self.beta = cg(
+            ap, (self.b_x, self.b_y, self.b_z), X, (self.d_x, self.d_y, self.d_z),
+            (self.r_x, self.r_y, self.r_z), (self.q_x, self.q_y, self.q_z), tol,
+            self.max_iter if max_iter is None else max_iter, self.history, raise_on_fail)
+        visc_writeback3d(self.gres, vx, vy, vz, self.x_x, self.x_y, self.x_z, sphi, sv)

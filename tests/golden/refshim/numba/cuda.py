@@ -1,0 +1,66 @@
+"""Container-only launch plumbing used by tests/golden/make_goldens.py.
+
+TEST INFRASTRUCTURE, never shipped on a product path.  The reference kernels
+are `@cuda.jit` Python functions.  This module runs such a function's
+*unmodified Python body* once per thread index of the launch
+(`kernel[blocks, threads](*args)`), sequentially under CPython, so every
+arithmetic statement executed is the reference's own source
+(SURVEY.md section 8(c), Appendix B).  It contains no solver arithmetic.
+
+Supported surface = exactly what the hot-path files touch:
+`jit` (bare and `device=True`), `grid(2|3)`, `local.array`, `synchronize`.
+"""
+import itertools
+
+import numpy as _np
+
+_tid = None  # thread index of the body currently being executed
+
+
+class _Kernel:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __getitem__(self, cfg):
+        blocks, threads = cfg[0], cfg[1]
+        if not isinstance(blocks, (tuple, list)):
+            blocks = (blocks,)
+        if not isinstance(threads, (tuple, list)):
+            threads = (threads,)
+        extent = tuple(int(b) * int(t) for b, t in zip(blocks, threads))
+
+        def launch(*args):
+            global _tid
+            fn = self.fn
+            for idx in itertools.product(*(range(e) for e in extent)):
+                _tid = idx
+                fn(*args)
+            _tid = None
+
+        return launch
+
+
+def jit(*args, **kwargs):
+    if len(args) == 1 and callable(args[0]) and not kwargs:
+        return _Kernel(args[0])
+    if kwargs.get("device", False):
+        return lambda fn: fn          # device function == plain call
+    return lambda fn: _Kernel(fn)
+
+
+def grid(ndim):
+    assert _tid is not None and len(_tid) == ndim
+    return _tid if ndim > 1 else _tid[0]
+
+
+class _Local:
+    @staticmethod
+    def array(n, dtype=_np.float64):
+        return _np.zeros(n, dtype=dtype)
+
+
+local = _Local()
+
+
+def synchronize():
+    pass
