@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- PressureCGSolver3D conjugate-gradient throughput on MI355X.
+
+A "step" is ONE CG iteration of the pressure solve (stencil apply + 2 dot
+products + the x/r/d updates: the loop solver/PressureCGSolver3D.py:207-221 of
+the reference) on a synthetic 256^3-per-GPU grid with fp32 state, inputs already
+resident in HBM.  value = cells x iterations / second over all GPUs (Mcells/s).
+
+N GPUs: one process per GPU (torch.distributed, RCCL), the grid sharded into
+x-slabs with a one-plane halo exchange of `d` and two scalar all-reduces per
+iteration (weak scaling: 256^3 cells per GPU; 8 GPUs = 512^3, BASELINE config 4).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "python-fluid-simulation_amd"), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+# global grid per world size: 256^3 cells per GPU, slabs along x (axis 0)
+GRIDS = {1: (256, 256, 256), 2: (512, 256, 256), 4: (512, 512, 256), 8: (512, 512, 512)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--n", type=int, default=0, help="override: cubic grid edge per GPU (default 256)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="CG iterations of the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, gres, scene_seed):
+    """The oracle (CPU restatement of the reference algorithm) timed on this box's
+    host cores on a bounded sample of the same workload: a few CG iterations of
+    the same 256^3 problem.  Reported beside the GPU number; not a target."""
+    import numpy as np
+    from mfs import scenes
+    try:
+        from oracle import cbaseline
+    except Exception:
+        cbaseline = None
+    from oracle import mfs_oracle as O
+    sc = scenes.pressure_scene_3d(gres, seed=scene_seed)
+    Nx, Ny, Nz = gres
+    wx, wy, wz = np.zeros((Nx + 1, Ny, Nz)), np.zeros((Nx, Ny + 1, Nz)), np.zeros((Nx, Ny, Nz + 1))
+    O.compute_solid_frac3d(gres, sc["sphi"], wx, wy, wz)
+    b = np.zeros(gres)
+    O.pressure_rhs3d(sc["cell_size"], gres, sc["vx"], sc["vy"], sc["vz"], sc["sphi"], sc["sv"], sc["lphi"], b, wx, wy, wz)
+    cells = Nx * Ny * Nz
+    if cbaseline is not None and cbaseline.available():
+        iters = args.cpu_iters or 40
+        dt, cores = cbaseline.time_cg(gres, b, sc["lphi"], wx, wy, wz, iters)
+        kind = "port"
+        sample = f"{iters} CG iterations of the same {Nx}x{Ny}x{Nz} problem, C/OpenMP restatement (oracle/mfs_oracle_c.c), fp64"
+    else:
+        iters = args.cpu_iters or 4
+        x, d, r, q = (np.zeros(gres) for _ in range(4))
+        ap = lambda V, Q: O.pressure_apply3d(gres, V[0], Q[0], wx, wy, wz, sc["lphi"])  # noqa: E731
+        t0 = time.perf_counter()
+        O.cg(ap, b, x, d, r, q, 0.0, iters, raise_on_fail=False)
+        dt = time.perf_counter() - t0
+        cores = 1
+        sample = f"{iters} CG iterations of the same {Nx}x{Ny}x{Nz} problem, numpy restatement (oracle/mfs_oracle.py), fp64"
+    return {"value": cells * iters / dt / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+            "sample": sample, "iters_per_s": iters / dt, "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mfs import _lib, scenes
+    from mfs.pcg import PcgEngine
+    from mfs import dist as mdist
+    import solver.PressureCGSolver3D as P
+    import solver.SolidFraction3D as S
+
+    _lib.load()
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4 if args.dtype == "f32" else 8
+    if args.n:
+        n = args.n
+        ggrid = {1: (n, n, n), 2: (2 * n, n, n), 4: (2 * n, 2 * n, n), 8: (2 * n, 2 * n, 2 * n)}[world]
+    else:
+        ggrid = GRIDS[world]
+    seed = 0
+
+    # ---- this rank's slab (global planes [a-1, b+1) incl. one ghost/boundary plane each side)
+    part = mdist.SlabPartition(ggrid[0], world, rank)
+    lo, hi = part.local_range            # cell planes held locally
+    lgres = (hi - lo, ggrid[1], ggrid[2])
+    sc = scenes.pressure_scene_3d(ggrid, seed=seed, x_range=(lo, hi), device=dev)
+    wx = torch.zeros((lgres[0] + 1, lgres[1], lgres[2]), dtype=tdt, device=dev)
+    wy = torch.zeros((lgres[0], lgres[1] + 1, lgres[2]), dtype=tdt, device=dev)
+    wz = torch.zeros((lgres[0], lgres[1], lgres[2] + 1), dtype=tdt, device=dev)
+    S.compute_solid_frac(lgres, sc["sphi"], wx, wy, wz)
+    b, x, d, r, q = (torch.zeros(lgres, dtype=tdt, device=dev) for _ in range(5))
+    P.initialize_solver(sc["cell_size"], lgres, sc["vx"], sc["vy"], sc["vz"], sc["sphi"], sc["sv"], sc["lphi"],
+                        b, wx, wy, wz)
+    lphi = sc["lphi"]
+    del sc
+    torch.cuda.empty_cache()
+    eng = PcgEngine(lgres, tdt, dev)
+    eng.setup(lphi, wx, wy, wz)
+    eng.bind(b, x, d, r, q)
+    cg = mdist.SlabCG(eng, part, d, dist if world > 1 else None)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    cg.begin(0.0)                          # tol = 0: never "converged", every step does full work
+    cg.iterate(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    cg.iterate(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    st = eng.poll()
+    assert st["iterations"] == args.warmup + args.steps, st
+    assert st["delta"] == st["delta"], "NaN residual"
+
+    owned_cells = part.global_cells(ggrid)
+    value = owned_cells * args.steps / dt / 1e6
+
+    # ---- roofline of the dominant kernel (stencil apply), measured with HIP events
+    rf = None
+    if rank == 0:
+        Nx, Ny, Nz = lgres
+        alg_bytes = (6 * Nx * Ny * Nz + 3 * Ny * Nz) * esz     # 6N^3+3N^2 scalars per apply
+        reps = max(20, min(args.steps, 200))
+        # (a) inside real CG iterations: events bracket each apply launch
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for s_ev, e_ev in evs:
+            s_ev.record()
+            eng.phase_apply(1, Nx - 1, True)
+            e_ev.record()
+            eng.phase_reduce(0); eng.phase_update_xr(); eng.phase_reduce(1); eng.phase_update_d()
+        torch.cuda.synchronize()
+        ms_cg = sum(s.elapsed_time(e) for s, e in evs) / reps
+        # (b) back-to-back applies between two events
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eng.apply(d, q)
+        s_ev.record()
+        for _ in range(reps):
+            eng.apply(d, q)
+        e_ev.record()
+        torch.cuda.synchronize()
+        ms_b2b = s_ev.elapsed_time(e_ev) / reps
+        achieved = alg_bytes / (ms_cg * 1e-3) / 1e9
+        traffic = None
+        pj = os.path.join(REPO, "profiles", "r01_pmc_apply.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        rf = {"bound": "hbm", "kernel": "k_pcg_apply", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+              "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5), "kernel_ms_back_to_back": round(ms_b2b, 5),
+              "achieved_back_to_back": round(alg_bytes / (ms_b2b * 1e-3) / 1e9, 1)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        cb = None
+        if world == 1 and not args.no_cpu_baseline:
+            del eng, cg, b, x, d, r, q, wx, wy, wz, lphi
+            torch.cuda.empty_cache()
+            cb = cpu_baseline(args, ggrid, seed)
+        iter_bytes = 15 * lgres[0] * lgres[1] * lgres[2] * esz
+        out = {
+            "metric": "PressureCGSolver3D CG throughput (cells x iterations / s)",
+            "value": round(value, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"PressureCGSolver3D {ggrid[0]}x{ggrid[1]}x{ggrid[2]} synthetic pool scene, "
+                                   f"fp32 state" if args.dtype == "f32" else
+                                   f"PressureCGSolver3D {ggrid[0]}x{ggrid[1]}x{ggrid[2]} synthetic pool scene, fp64 state",
+                       "grid": list(ggrid), "cells_per_gpu": lgres[0] * lgres[1] * lgres[2],
+                       "decomposition": f"x-slabs x{world}" if world > 1 else "single domain",
+                       "step": "one CG iteration (apply + 2 dots + x/r/d updates)"},
+            "iters_per_s": round(args.steps / dt, 2),
+            "cg_iteration_hbm_gbs": round(iter_bytes / (dt / args.steps) / 1e9, 1),
+            "roofline": rf,
+        }
+        if cb is not None:
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

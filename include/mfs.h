@@ -1,0 +1,149 @@
+/* mfs.h -- C ABI of libmfs_hip.so: the MI355X (gfx950) pressure / viscosity CG path.
+ *
+ * The reference (SSTDV-Project/python-fluid-simulation) has no FFI: its `solver/`
+ * package is Python that launches numba-CUDA kernels and cupy expressions
+ * directly.  This header is therefore the boundary a maintainer binds INSTEAD of
+ * those launches: every entry point names the reference function it replaces
+ * (file:line, relative to the reference repo root).  The Python classes in
+ * python-fluid-simulation_amd/solver/ bind it with ctypes.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every array pointer is a DEVICE pointer unless
+ *    the parameter name ends in `_host`.  No allocation happens behind the ABI:
+ *    workspaces are sized by a query and handed in by the caller.
+ *  - arrays are C-order with the reference's axis order [x,y,z] (z contiguous):
+ *    cell arrays (Nx,Ny,Nz); face arrays vx/wx (Nx+1,Ny,Nz), vy/wy (Nx,Ny+1,Nz),
+ *    vz/wz (Nx,Ny,Nz+1); doubled grid sphi/lvol (2Nx+1,2Ny+1,2Nz+1), sv (...,3).
+ *  - `*_dt` arguments are mfs_dtype codes describing the element type of the
+ *    array group they follow.
+ *  - every call is asynchronous on `stream` (a hipStream_t) unless documented
+ *    otherwise; return value is an mfs_status.  Nothing throws.
+ */
+#ifndef MFS_H
+#define MFS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFS_ABI_VERSION 1
+
+typedef enum { MFS_F32 = 0, MFS_F64 = 1 } mfs_dtype;
+
+typedef enum {
+  MFS_OK = 0,
+  MFS_NOT_CONVERGED = 1,  /* reference: raise ValueError("Failed to converge!"), PressureCGSolver3D.py:222-223 */
+  MFS_E_INVALID = -1,     /* bad argument (null pointer, bad dtype, bad size, misuse) */
+  MFS_E_HIP = -2,         /* a HIP runtime call failed; see mfs_last_error() */
+  MFS_E_NODEVICE = -3     /* no gfx950 device visible */
+} mfs_status;
+
+typedef void* mfs_stream; /* hipStream_t */
+
+int mfs_abi_version(void);
+/* thread-local text of the last failure on this thread ("" if none) */
+const char* mfs_last_error(void);
+/* name of the device the current HIP context runs on, e.g. "gfx950:..."; host call */
+int mfs_device_name(char* buf_host, size_t cap);
+
+/* ------------------------------------------------------------------------- */
+/* Solid fractions                                                           */
+/* ------------------------------------------------------------------------- */
+/* replaces compute_solid_frac -- solver/SolidFraction3D.py:6-32.
+ * Writes w*[0:N] on every axis; the upper faces w*[N] are left untouched.      */
+int mfs_solid_frac3d(const int64_t gres[3], const void* sphi, int sphi_dt,
+                     void* wx, void* wy, void* wz, int w_dt, mfs_stream stream);
+/* replaces compute_solid_frac -- solver/SolidFraction2D.py:6-26 */
+int mfs_solid_frac2d(const int64_t gres[2], const void* sphi, int sphi_dt,
+                     void* wx, void* wy, int w_dt, mfs_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* Pressure, 3D -- stateless kernels (the reference's module-level functions)  */
+/* ------------------------------------------------------------------------- */
+/* replaces initialize_solver -- solver/PressureCGSolver3D.py:6-50,155-159 */
+int mfs_pressure_rhs3d(const int64_t gres[3], const double cell_size[3],
+                       const void* vx, const void* vy, const void* vz, int v_dt,
+                       const void* sv, int sv_dt, const void* lphi, int lphi_dt,
+                       const void* wx, const void* wy, const void* wz, int w_dt,
+                       void* b, int b_dt, mfs_stream stream);
+/* replaces matvecmul -- solver/PressureCGSolver3D.py:52-130,161-165.
+ * Ghost-fluid 7-point operator straight from lphi and the face weights; boundary
+ * cells of `out` are not written.  v,out share `dt`.                            */
+int mfs_pressure_apply3d(const int64_t gres[3], const void* v, void* out, int dt,
+                         const void* wx, const void* wy, const void* wz, int w_dt,
+                         const void* lphi, int lphi_dt, mfs_stream stream);
+/* replaces apply_pressure -- solver/PressureCGSolver3D.py:132-153,167-171 (in place on vx,vy,vz) */
+int mfs_pressure_update3d(const int64_t gres[3], const double cell_size[3],
+                          void* vx, void* vy, void* vz, int v_dt, const void* pv, int pv_dt,
+                          const void* wx, const void* wy, const void* wz, int w_dt,
+                          const void* sv, int sv_dt, const void* lphi, int lphi_dt,
+                          mfs_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* Pressure, 3D -- the CG engine (replaces the loop PressureCGSolver3D.py:198-223) */
+/* ------------------------------------------------------------------------- */
+typedef struct mfs_pcg3d mfs_pcg3d;
+
+/* bytes of device workspace mfs_pcg3d_create needs for this grid / state dtype */
+size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt);
+/* number of doubles in the residual-history buffer kept inside the workspace */
+int64_t mfs_pcg3d_history_capacity(void);
+/* host call. `workspace` must be 256-byte aligned device memory of at least
+ * mfs_pcg3d_workspace_bytes(); it is zeroed asynchronously on `stream`.         */
+int mfs_pcg3d_create(mfs_pcg3d** out_host, const int64_t gres[3], int dt,
+                     void* workspace, size_t workspace_bytes, mfs_stream stream);
+int mfs_pcg3d_destroy(mfs_pcg3d* h);
+/* once per solve: fold lphi + face weights into the 4 coefficient arrays the
+ * per-iteration stencil reads (diag, and fluid-masked lower-face weights).     */
+int mfs_pcg3d_setup(mfs_pcg3d* h, const void* lphi, int lphi_dt,
+                    const void* wx, const void* wy, const void* wz, int w_dt, mfs_stream stream);
+/* out = A v on cell planes [x_begin, x_end) (clipped to the interior 1..Nx-2);
+ * the per-iteration hot kernel.  Also leaves sum(v*out) partials in the handle. */
+int mfs_pcg3d_apply(mfs_pcg3d* h, const void* v, void* out, int64_t x_begin, int64_t x_end,
+                    mfs_stream stream);
+/* CG vectors: caller-owned cell arrays of the handle's dtype (CGSolverBuffer.py:3-8 + solver.x) */
+int mfs_pcg3d_bind(mfs_pcg3d* h, void* b, void* x, void* d, void* r, void* q);
+/* x*=0; q=A x; d=r=b-q; delta0=sum r^2; done=(delta0<tol^2)   (PressureCGSolver3D.py:198-206) */
+int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream);
+/* enqueue n CG iterations (lines 207-221); iterations after convergence are device-side no-ops */
+int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream);
+/* synchronises `stream`, then reports the device-resident solver state. host call. */
+int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
+                   double* delta_host, double* alpha_host, double* beta_host);
+/* begin + iterate/poll until done or max_iter; MFS_OK or MFS_NOT_CONVERGED. host-synchronous. */
+int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_every,
+                    mfs_stream stream, int64_t* iters_host);
+/* copies [delta0, dq1, delta1, dq2, delta2, ...] (first `cap` values) to the host; returns count or <0 */
+int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_stream stream);
+
+/* -- single phases of one iteration, for the slab-decomposed multi-GPU driver.
+ * Order per iteration k:  [halo exchange of d] phase_apply(ranges...) ->
+ * phase_reduce(0) -> [all-reduce scalars[DQ]] -> phase_update_xr ->
+ * phase_reduce(1) -> [all-reduce scalars[RR]] -> phase_update_d.               */
+int mfs_pcg3d_phase_apply(mfs_pcg3d* h, int64_t x_begin, int64_t x_end, int first, mfs_stream stream);
+int mfs_pcg3d_phase_reduce(mfs_pcg3d* h, int which, mfs_stream stream);
+int mfs_pcg3d_phase_update_xr(mfs_pcg3d* h, mfs_stream stream);
+int mfs_pcg3d_phase_update_d(mfs_pcg3d* h, mfs_stream stream);
+/* begin, split around the one reduction it contains: begin_local -> [all-reduce RR] -> begin_finish */
+int mfs_pcg3d_begin_local(mfs_pcg3d* h, double tol, mfs_stream stream);
+int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream);
+/* device pointer to the engine's double[MFS_PCG_NSCALARS] block and slot indices */
+#define MFS_PCG_NSCALARS 16
+#define MFS_PCG_S_DQ 0      /* sum d.q of the current iteration */
+#define MFS_PCG_S_RR 1      /* sum r.r produced by the latest update (delta_new) */
+#define MFS_PCG_S_DELTA 2   /* delta the current iteration started from */
+#define MFS_PCG_S_TOL2 3
+#define MFS_PCG_S_DONE 4
+#define MFS_PCG_S_ITERS 5
+#define MFS_PCG_S_ALPHA 6
+#define MFS_PCG_S_BETA 7
+#define MFS_PCG_S_LASTRR 8  /* r.r of the last completed iteration (what the reference keeps in self.delta) */
+void* mfs_pcg3d_scalars(mfs_pcg3d* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFS_H */

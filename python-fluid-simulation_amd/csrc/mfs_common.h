@@ -1,0 +1,85 @@
+// mfs_common.h -- shared device/host helpers for libmfs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mfs.h"
+
+namespace mfs {
+
+// ---------------------------------------------------------------- errors ----
+void set_error(const char* fmt, ...);
+
+#define MFS_HIP_TRY(expr)                                                            \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      ::mfs::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return MFS_E_HIP;                                                              \
+    }                                                                                \
+  } while (0)
+
+#define MFS_REQUIRE(cond, msg)                                                       \
+  do {                                                                               \
+    if (!(cond)) {                                                                   \
+      ::mfs::set_error("%s:%d: invalid argument: %s (%s)", __FILE__, __LINE__, msg, #cond); \
+      return MFS_E_INVALID;                                                          \
+    }                                                                                \
+  } while (0)
+
+#define MFS_LAUNCH_CHECK() MFS_HIP_TRY(hipGetLastError())
+
+static inline bool dtype_ok(int dt) { return dt == MFS_F32 || dt == MFS_F64; }
+static inline size_t dtype_size(int dt) { return dt == MFS_F32 ? 4 : 8; }
+
+// ------------------------------------------------------- typed load/store ---
+// Once-per-solve kernels take arrays of either element type; the dtype code is
+// wave-uniform, so the branch costs nothing.  Arithmetic is always fp64 there.
+__device__ __forceinline__ double ldx(const void* p, int dt, int64_t i) {
+  return dt == MFS_F32 ? (double)((const float*)p)[i] : ((const double*)p)[i];
+}
+__device__ __forceinline__ void stx(void* p, int dt, int64_t i, double v) {
+  if (dt == MFS_F32) ((float*)p)[i] = (float)v; else ((double*)p)[i] = v;
+}
+
+// ------------------------------------------------------------ reductions ----
+constexpr int kWave = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;  // lane 0 holds the wave total
+}
+
+// Block total in thread 0 (deterministic: fixed shuffle tree, then waves in order).
+template <int BLOCK>
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double s_part[BLOCK / kWave];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  if (lane == 0) s_part[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < BLOCK / kWave; ++w) t += s_part[w];
+  }
+  __syncthreads();
+  return t;
+}
+
+// 16-byte vector of T: float4 / double2 without dragging in operator overloads.
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Vec {
+  T v[VEC];
+};
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<double> { static constexpr int N = 2; };
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace mfs

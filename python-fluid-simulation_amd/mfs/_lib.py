@@ -1,0 +1,107 @@
+"""ctypes binding of libmfs_hip.so (the C ABI declared in include/mfs.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails,
+this module raises.  torch is imported before the library is opened so that the
+library's dependency on libamdhip64.so.7 resolves to the HIP runtime PyTorch
+already loaded -- one runtime per process, so torch streams / device pointers are
+valid inside the kernels' launches.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfs_hip.so")
+
+MFS_F32, MFS_F64 = 0, 1
+MFS_OK, MFS_NOT_CONVERGED = 0, 1
+ABI_VERSION = 1
+
+# scalar slots of the CG engine's device block (include/mfs.h)
+S_DQ, S_RR, S_DELTA, S_TOL2, S_DONE, S_ITERS, S_ALPHA, S_BETA, S_LASTRR = range(9)
+NSCALARS = 16
+
+
+class MfsError(RuntimeError):
+    pass
+
+
+_p, _i, _i64, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+_pi64 = C.POINTER(C.c_int64)
+_pd = C.POINTER(C.c_double)
+_pint = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes).  Mirrors include/mfs.h one to one
+# (tests/test_abi.py checks the header against this table and the built .so).
+SIGNATURES = {
+    "mfs_abi_version": (_i, []),
+    "mfs_last_error": (C.c_char_p, []),
+    "mfs_device_name": (_i, [C.c_char_p, _sz]),
+    "mfs_solid_frac3d": (_i, [_pi64, _p, _i, _p, _p, _p, _i, _p]),
+    "mfs_solid_frac2d": (_i, [_pi64, _p, _i, _p, _p, _i, _p]),
+    "mfs_pressure_rhs3d": (_i, [_pi64, _pd, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p]),
+    "mfs_pressure_apply3d": (_i, [_pi64, _p, _p, _i, _p, _p, _p, _i, _p, _i, _p]),
+    "mfs_pressure_update3d": (_i, [_pi64, _pd, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
+    "mfs_pcg3d_workspace_bytes": (_sz, [_pi64, _i]),
+    "mfs_pcg3d_history_capacity": (_i64, []),
+    "mfs_pcg3d_create": (_i, [C.POINTER(_p), _pi64, _i, _p, _sz, _p]),
+    "mfs_pcg3d_destroy": (_i, [_p]),
+    "mfs_pcg3d_setup": (_i, [_p, _p, _i, _p, _p, _p, _i, _p]),
+    "mfs_pcg3d_apply": (_i, [_p, _p, _p, _i64, _i64, _p]),
+    "mfs_pcg3d_bind": (_i, [_p, _p, _p, _p, _p, _p]),
+    "mfs_pcg3d_begin": (_i, [_p, _d, _p]),
+    "mfs_pcg3d_iterate": (_i, [_p, _i64, _p]),
+    "mfs_pcg3d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
+    "mfs_pcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
+    "mfs_pcg3d_history": (_i64, [_p, _pd, _i64, _p]),
+    "mfs_pcg3d_phase_apply": (_i, [_p, _i64, _i64, _i, _p]),
+    "mfs_pcg3d_phase_reduce": (_i, [_p, _i, _p]),
+    "mfs_pcg3d_phase_update_xr": (_i, [_p, _p]),
+    "mfs_pcg3d_phase_update_d": (_i, [_p, _p]),
+    "mfs_pcg3d_begin_local": (_i, [_p, _d, _p]),
+    "mfs_pcg3d_begin_finish": (_i, [_p, _p]),
+    "mfs_pcg3d_scalars": (_p, [_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Open libmfs_hip.so (once) and type every entry point.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MI355X HIP kernels are not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C python-fluid-simulation_amd/csrc`). "
+            "There is no CPU fallback for the solver path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.mfs_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"libmfs_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    """Raise MfsError for negative statuses; returns the status otherwise."""
+    if status < 0:
+        msg = load().mfs_last_error().decode(errors="replace")
+        raise MfsError(f"{what or 'libmfs_hip'} failed with status {status}: {msg}")
+    return status
+
+
+def i64x(vals):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def f64x(vals):
+    return (C.c_double * len(vals))(*[float(v) for v in vals])

@@ -1,0 +1,119 @@
+"""Python owner of one `mfs_pcg3d` engine handle (include/mfs.h): allocates the
+device workspace with torch, keeps it alive, and exposes the C entry points."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, tensors as T
+
+
+class PcgEngine:
+    def __init__(self, gres, dtype, device=None):
+        self.lib = _lib.load()
+        self.gres = T.as_gres(gres)
+        if len(self.gres) != 3:
+            raise ValueError("PcgEngine is 3D")
+        self.dtype = T.state_dtype(dtype)
+        self.code = _lib.MFS_F32 if self.dtype == torch.float32 else _lib.MFS_F64
+        self.device = torch.device("cuda" if device is None else device)
+        g = _lib.i64x(self.gres)
+        nbytes = int(self.lib.mfs_pcg3d_workspace_bytes(g, self.code))
+        if nbytes <= 0:
+            raise _lib.MfsError("mfs_pcg3d_workspace_bytes returned 0")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mfs_pcg3d_create(C.byref(h), g, self.code, T.ptr(self.workspace), nbytes, T.stream()),
+                       "mfs_pcg3d_create")
+        self.h = h
+        # the engine's scalar block is the first 128 bytes of the workspace
+        self.scalars = self.workspace[: _lib.NSCALARS * 8].view(torch.float64)
+        assert self.scalars.data_ptr() == self.lib.mfs_pcg3d_scalars(self.h)
+        self._bound = None
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.mfs_pcg3d_destroy(h)
+            except Exception:
+                pass
+
+    # -- once per solve ------------------------------------------------------
+    def setup(self, lphi, wx, wy, wz):
+        g = self.gres
+        lphi = T.dev(lphi, "lphi", g)
+        wx, wy, wz = (T.dev(w, n, T.face_shape(g, a)) for a, (w, n) in enumerate(((wx, "wx"), (wy, "wy"), (wz, "wz"))))
+        if not (wx.dtype == wy.dtype == wz.dtype):
+            raise TypeError("wx, wy, wz must share a dtype")
+        _lib.check(self.lib.mfs_pcg3d_setup(self.h, T.ptr(lphi), T.code(lphi), T.ptr(wx), T.ptr(wy), T.ptr(wz),
+                                            T.code(wx), T.stream()), "mfs_pcg3d_setup")
+
+    def bind(self, b, x, d, r, q):
+        ts = [T.dev(a, n, self.gres) for a, n in ((b, "b"), (x, "x"), (d, "d"), (r, "r"), (q, "q"))]
+        for t in ts:
+            if t.dtype != self.dtype:
+                raise TypeError(f"CG vectors must be {self.dtype}, got {t.dtype}")
+        _lib.check(self.lib.mfs_pcg3d_bind(self.h, *[T.ptr(t) for t in ts]), "mfs_pcg3d_bind")
+        self._bound = ts          # keep the tensors alive while the engine points at them
+
+    # -- the hot kernel on its own ---------------------------------------------
+    def apply(self, v, out, x_begin=None, x_end=None):
+        v = T.dev(v, "v", self.gres)
+        out = T.dev(out, "out", self.gres)
+        if v.dtype != self.dtype or out.dtype != self.dtype:
+            raise TypeError(f"apply operands must be {self.dtype}")
+        xb = 1 if x_begin is None else int(x_begin)
+        xe = self.gres[0] - 1 if x_end is None else int(x_end)
+        _lib.check(self.lib.mfs_pcg3d_apply(self.h, T.ptr(v), T.ptr(out), xb, xe, T.stream()), "mfs_pcg3d_apply")
+
+    # -- CG ----------------------------------------------------------------------
+    def begin(self, tol):
+        _lib.check(self.lib.mfs_pcg3d_begin(self.h, float(tol), T.stream()), "mfs_pcg3d_begin")
+
+    def iterate(self, n):
+        _lib.check(self.lib.mfs_pcg3d_iterate(self.h, int(n), T.stream()), "mfs_pcg3d_iterate")
+
+    def poll(self):
+        it, done = C.c_int64(), C.c_int()
+        delta, alpha, beta = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib.mfs_pcg3d_poll(self.h, T.stream(), C.byref(it), C.byref(done), C.byref(delta),
+                                           C.byref(alpha), C.byref(beta)), "mfs_pcg3d_poll")
+        return dict(iterations=it.value, done=bool(done.value), delta=delta.value, alpha=alpha.value,
+                    beta=beta.value)
+
+    def solve(self, tol, max_iter, check_every=32):
+        it = C.c_int64()
+        st = _lib.check(self.lib.mfs_pcg3d_solve(self.h, float(tol), int(max_iter), int(check_every), T.stream(),
+                                                 C.byref(it)), "mfs_pcg3d_solve")
+        return st == _lib.MFS_OK, it.value
+
+    def history(self):
+        cap = int(self.lib.mfs_pcg3d_history_capacity())
+        buf = np.empty(cap, dtype=np.float64)
+        n = self.lib.mfs_pcg3d_history(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), cap, T.stream())
+        _lib.check(int(n), "mfs_pcg3d_history")
+        return buf[: int(n)].copy()
+
+    # -- single phases (multi-GPU driver) ------------------------------------------
+    def phase_apply(self, xb, xe, first):
+        _lib.check(self.lib.mfs_pcg3d_phase_apply(self.h, int(xb), int(xe), int(bool(first)), T.stream()),
+                   "mfs_pcg3d_phase_apply")
+
+    def phase_reduce(self, which):
+        _lib.check(self.lib.mfs_pcg3d_phase_reduce(self.h, int(which), T.stream()), "mfs_pcg3d_phase_reduce")
+
+    def phase_update_xr(self):
+        _lib.check(self.lib.mfs_pcg3d_phase_update_xr(self.h, T.stream()), "mfs_pcg3d_phase_update_xr")
+
+    def phase_update_d(self):
+        _lib.check(self.lib.mfs_pcg3d_phase_update_d(self.h, T.stream()), "mfs_pcg3d_phase_update_d")
+
+    def begin_local(self, tol):
+        _lib.check(self.lib.mfs_pcg3d_begin_local(self.h, float(tol), T.stream()), "mfs_pcg3d_begin_local")
+
+    def begin_finish(self):
+        _lib.check(self.lib.mfs_pcg3d_begin_finish(self.h, T.stream()), "mfs_pcg3d_begin_finish")

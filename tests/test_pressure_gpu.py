@@ -1,0 +1,259 @@
+"""Parity of the HIP pressure path (through the C ABI) against the oracle, the
+golden vectors, and size-independent properties at BASELINE sizes.  GPU only.
+
+Tolerances (stated per SURVEY.md 8(c)/BASELINE.md):
+  fp64 state : per-kernel outputs 1e-12 rel (same fp64 operations, FMA contraction
+               and reduction order may differ); CG residual history 1e-9 rel,
+               iteration count exact, solution / velocities 1e-8 rel.
+  fp32 state : fp32 STORAGE with fp64 register arithmetic; compared with the fp64
+               reference history at 1e-5 rel over the first FP32_WINDOW iterations
+               (north_star's bar) and 1e-3 rel over the first half of the solve.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_names
+from mfs import scenes
+from oracle import mfs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+FP32_WINDOW = 10
+
+
+def T(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def close(a, b, rtol, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), 1e-300)
+    np.testing.assert_allclose(a.astype(np.float64), b, rtol=rtol, atol=rtol * scale, err_msg=what)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mfs import _lib
+    _lib.load()
+    import solver.CGSolverBuffer as B
+    import solver.PressureCGSolver3D as P
+    import solver.SolidFraction3D as S
+    return B, P, S
+
+
+@pytest.mark.parametrize("name", golden_names("p3d_"))
+@pytest.mark.parametrize("wdt", [torch.float64, torch.float32])
+def test_solid_frac_rhs_apply_vs_golden(mods, name, wdt):
+    B, P, S = mods
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    Nx, Ny, Nz = gres
+    wx = torch.full((Nx + 1, Ny, Nz), -3.0, dtype=wdt, device=DEV)
+    wy = torch.full((Nx, Ny + 1, Nz), -3.0, dtype=wdt, device=DEV)
+    wz = torch.full((Nx, Ny, Nz + 1), -3.0, dtype=wdt, device=DEV)
+    S.compute_solid_frac(gres, T(g["sphi"]), wx, wy, wz)
+    # quarters are exact in fp32 too -> bit-exact in both dtypes
+    assert np.array_equal(wx[:Nx].cpu().numpy(), g["wx"][:Nx])
+    assert np.array_equal(wy[:, :Ny].cpu().numpy(), g["wy"][:, :Ny])
+    assert np.array_equal(wz[:, :, :Nz].cpu().numpy(), g["wz"][:, :, :Nz])
+    assert (wx[Nx] == -3).all() and (wy[:, Ny] == -3).all() and (wz[:, :, Nz] == -3).all()  # untouched (Q8)
+
+    gwx, gwy, gwz = T(g["wx"]), T(g["wy"]), T(g["wz"])
+    b = torch.full(gres, 5.0, dtype=torch.float64, device=DEV)
+    P.initialize_solver(g["bound_size"] / g["gres"], gres, T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"]),
+                        T(g["sphi"]), T(g["sv"]), T(g["lphi"]), b, gwx, gwy, gwz)
+    bi = b.cpu().numpy()
+    close(bi[1:-1, 1:-1, 1:-1], g["b"][1:-1, 1:-1, 1:-1], 1e-12, "rhs")
+    assert (bi[0] == 5).all() and (bi[:, 0] == 5).all() and (bi[:, :, -1] == 5).all()   # boundary untouched
+
+    out = torch.full(gres, 7.0, dtype=torch.float64, device=DEV)
+    P.matvecmul(gres, T(g["rv"]), out, gwx, gwy, gwz, T(g["lphi"]))
+    close(out, g["qr"], 1e-12, "matvecmul")          # includes the untouched 7.0 boundary
+
+
+@pytest.mark.parametrize("name", golden_names("p3d_"))
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_engine_apply_matches_reference_operator(mods, name, dt):
+    """the per-iteration kernel (precomputed coefficients) == the operator from lphi,w."""
+    from mfs.pcg import PcgEngine
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    eng = PcgEngine(gres, dt, DEV)
+    eng.setup(T(g["lphi"]), T(g["wx"]), T(g["wy"]), T(g["wz"]))
+    v = T(g["rv"], dt)
+    out = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    eng.apply(v, out)
+    ref = np.full(gres, 7.0)
+    O.pressure_apply3d(gres, v.cpu().numpy().astype(np.float64), ref, g["wx"], g["wy"], g["wz"], g["lphi"])
+    close(out, ref, 1e-12 if dt == torch.float64 else 2e-7, "engine apply")
+    # plane-range form: two halves == whole
+    out2 = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    mid = gres[0] // 2
+    eng.apply(v, out2, 1, mid)
+    eng.apply(v, out2, mid, gres[0] - 1)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("name", golden_names("p3d_"))
+def test_solve_fp64_vs_golden(mods, name):
+    B, P, S = mods
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    buf = B.CGSolverBuffer(gres, precision="fp64", device=DEV)
+    s = P.PressureCGSolver3D(buf, gres, g["bound_size"], check_every=7)
+    vx, vy, vz = T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])
+    s.solve(vx, vy, vz, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), tol=float(g["tol"]))
+    assert s.iterations == int(g["iters"])
+    close(s.history, g["history"], 1e-9, "history")
+    close(s.x, g["x"], 1e-8, "x")
+    for a, k in ((vx, "out_vx"), (vy, "out_vy"), (vz, "out_vz")):
+        assert a.dtype == torch.as_tensor(g[k]).dtype
+        close(a, g[k], 2e-6 if a.dtype == torch.float32 else 1e-8, k)
+    assert abs(s.delta - float(g["delta"])) <= 1e-9 * float(g["delta"])
+    assert abs(s.alpha - float(g["alpha"])) <= 1e-8 * abs(float(g["alpha"]))
+    assert abs(s.beta - float(g["beta"])) <= 1e-8 * abs(float(g["beta"]))
+    # caller-supplied weights (the notebook passes DensitySolver.wx, ipynb:4648): same result
+    buf2 = B.CGSolverBuffer(gres, precision="fp64", device=DEV)
+    s2 = P.PressureCGSolver3D(buf2, gres, g["bound_size"])
+    v2 = [T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])]
+    s2.solve(*v2, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), wx=T(g["wx"]), wy=T(g["wy"]), wz=T(g["wz"]),
+             tol=float(g["tol"]))
+    assert s2.iterations == s.iterations and torch.equal(v2[0], vx) and torch.equal(s2.x, s.x)
+
+
+@pytest.mark.parametrize("name", golden_names("p3d_"))
+def test_solve_fp32_state_vs_golden(mods, name):
+    B, P, S = mods
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    buf = B.CGSolverBuffer(gres, precision="fp32", device=DEV)
+    s = P.PressureCGSolver3D(buf, gres, g["bound_size"])
+    vx, vy, vz = T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])
+    s.solve(vx, vy, vz, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), tol=float(g["tol"]))
+    h, hg = s.history, g["history"]
+    w = 2 * FP32_WINDOW + 1
+    np.testing.assert_allclose(h[:w], hg[:w], rtol=1e-5)
+    half = (min(len(h), len(hg)) // 2) | 1
+    np.testing.assert_allclose(h[:half], hg[:half], rtol=1e-3)
+    assert abs(s.iterations - int(g["iters"])) <= max(2, int(g["iters"]) // 10)
+    close(s.x, g["x"], 1e-4, "x fp32")
+    for a, k in ((vx, "out_vx"), (vy, "out_vy"), (vz, "out_vz")):
+        close(a, g[k], 1e-4, k)
+
+
+def test_seeded_scene_vs_oracle_nonmultiple_sizes(mods):
+    """ragged sizes (odd Nz -> scalar kernels; fp32 velocities; solid velocity)"""
+    B, P, S = mods
+    for gres, seed in (((9, 11, 13), 21), ((6, 5, 7), 22), ((32, 8, 12), 23)):
+        sc = scenes.pressure_scene_3d(gres, seed=seed, solid_velocity=True)
+        ref = O.PressureCGSolver3D(gres, sc["bound_size"])
+        rv = [sc["vx"].copy(), sc["vy"].copy(), sc["vz"].copy()]
+        ref.solve(*rv, sc["sphi"], sc["sv"], sc["lphi"])
+        buf = B.CGSolverBuffer(gres, device=DEV)
+        s = P.PressureCGSolver3D(buf, gres, sc["bound_size"])
+        v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
+        s.solve(*v, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]))
+        assert s.iterations == ref.iterations
+        close(s.history, np.array(ref.history), 1e-9)
+        for a, b in zip(v, rv):
+            close(a, b, 2e-6)
+
+
+def test_failed_to_converge_raises(mods):
+    B, P, S = mods
+    g = golden("p3d_a_12")
+    gres = tuple(int(v) for v in g["gres"])
+    buf = B.CGSolverBuffer(gres, device=DEV)
+    s = P.PressureCGSolver3D(buf, gres, g["bound_size"])
+    s.max_iter = 5
+    with pytest.raises(ValueError, match="Failed to converge!"):
+        s.solve(T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"]), T(g["sphi"]), T(g["sv"]), T(g["lphi"]))
+    assert s.iterations == 5
+    np.testing.assert_allclose(s.history, g["history"][:11], rtol=1e-9)
+
+
+def test_already_converged_rhs_does_no_iterations(mods):
+    B, P, S = mods
+    gres = (8, 8, 8)
+    sc = scenes.pressure_scene_3d(gres, seed=1)
+    buf = B.CGSolverBuffer(gres, device=DEV)
+    s = P.PressureCGSolver3D(buf, gres, sc["bound_size"])
+    z = lambda k: torch.zeros_like(T(sc[k]))  # noqa: E731
+    vx, vy, vz = z("vx"), z("vy"), z("vz")
+    s.solve(vx, vy, vz, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]))
+    assert s.iterations == 0 and s.delta == 0.0
+    assert not vx.any() and not vy.any() and not vz.any()
+
+
+@pytest.mark.parametrize("dt,N", [(torch.float32, 256), (torch.float64, 128)])
+def test_full_size_properties(mods, dt, N):
+    """BASELINE sizes: properties that need no oracle run -- symmetry <Au,v>=<u,Av>,
+    positivity, A.0=0, boundary untouched, plane-range decomposition, determinism,
+    and agreement of the precomputed-coefficient kernel with the direct operator."""
+    B, P, S = mods
+    from mfs.pcg import PcgEngine
+    gres = (N, N, N)
+    sc = scenes.pressure_scene_3d(gres, seed=4, device=DEV)
+    wx = torch.zeros((N + 1, N, N), dtype=torch.float64, device=DEV)
+    wy = torch.zeros((N, N + 1, N), dtype=torch.float64, device=DEV)
+    wz = torch.zeros((N, N, N + 1), dtype=torch.float64, device=DEV)
+    S.compute_solid_frac(gres, sc["sphi"], wx, wy, wz)
+    assert set(torch.unique(wx).tolist()) <= {0.0, 0.25, 0.5, 0.75, 1.0}
+    eng = PcgEngine(gres, dt, DEV)
+    eng.setup(sc["lphi"], wx, wy, wz)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    u = torch.randn(gres, generator=gen, device=DEV, dtype=dt)
+    v = torch.randn(gres, generator=gen, device=DEV, dtype=dt)
+    for t in (u, v):   # boundary cells carry no DOF in the CG (d is 0 there)
+        t[0] = 0; t[-1] = 0; t[:, 0] = 0; t[:, -1] = 0; t[:, :, 0] = 0; t[:, :, -1] = 0
+    Au = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    Av = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    eng.apply(u, Au)
+    eng.apply(v, Av)
+    for t in (Au, Av):
+        assert (t[0] == 7).all() and (t[-1] == 7).all() and (t[:, 0] == 7).all() and (t[:, :, -1] == 7).all()
+        t[0] = 0; t[-1] = 0; t[:, 0] = 0; t[:, -1] = 0; t[:, :, 0] = 0; t[:, :, -1] = 0
+    uAv = (u.double() * Av.double()).sum().item()
+    vAu = (v.double() * Au.double()).sum().item()
+    uAu = (u.double() * Au.double()).sum().item()
+    tol = 1e-11 if dt == torch.float64 else 2e-6
+    assert abs(uAv - vAu) <= tol * max(abs(uAv), abs(uAu)), (uAv, vAu)
+    assert uAu > 0
+    # direct operator from lphi / w agrees
+    if dt == torch.float64:
+        ref = torch.zeros(gres, dtype=dt, device=DEV)
+        P.matvecmul(gres, u, ref, wx, wy, wz, sc["lphi"])
+        assert torch.allclose(ref, Au, rtol=1e-12, atol=1e-12 * Au.abs().max().item())
+    # A.0 = 0, determinism
+    z = torch.zeros(gres, dtype=dt, device=DEV)
+    Az = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    eng.apply(z, Az)
+    assert (Az[1:-1, 1:-1, 1:-1] == 0).all()
+    Au2 = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    eng.apply(u, Au2)
+    Au2[0] = 0; Au2[-1] = 0; Au2[:, 0] = 0; Au2[:, -1] = 0; Au2[:, :, 0] = 0; Au2[:, :, -1] = 0
+    assert torch.equal(Au, Au2)
+
+
+def test_full_size_solve_runs_and_reduces_divergence(mods):
+    """128^3 fp32 state, end to end through the drop-in class: converges, is
+    reproducible bit for bit, and the CG energy decreases (residual history sane)."""
+    B, P, S = mods
+    gres = (128, 128, 128)
+    sc = scenes.pressure_scene_3d(gres, seed=9, device=DEV)
+    outs = []
+    for _ in range(2):
+        buf = B.CGSolverBuffer(gres, precision="fp32", device=DEV)
+        s = P.PressureCGSolver3D(buf, gres, sc["bound_size"])
+        v = [sc["vx"].clone(), sc["vy"].clone(), sc["vz"].clone()]
+        s.solve(*v, sc["sphi"], sc["sv"], sc["lphi"], tol=1e-2)
+        outs.append((s.iterations, s.history, v))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
+    h = outs[0][1]
+    assert h[-1] < 1e-4 and h[-1] < 1e-6 * h[0]
+    assert (h[1::2] > 0).all()          # d.Ad > 0 : operator positive on the Krylov directions
