@@ -102,9 +102,10 @@ k_pcg_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ 
   const int ry = Ny - 2;
   const int64_t ipp = (int64_t)ry * nzv;  // items per plane
   const int np = xe - xb;
-  const int xcd = blockIdx.x % kNumXcd, slot = blockIdx.x / kNumXcd;
-  const int nblk = (gridDim.x - xcd + kNumXcd - 1) / kNumXcd;
-  const int p0 = (int)((int64_t)np * xcd / kNumXcd), p1 = (int)((int64_t)np * (xcd + 1) / kNumXcd);
+  const int nch = min((int)gridDim.x, kNumXcd);  // plane chunks = XCD labels that own at least one block
+  const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
+  const int nblk = (gridDim.x - xcd + nch - 1) / nch;
+  const int p0 = (int)((int64_t)np * xcd / nch), p1 = (int)((int64_t)np * (xcd + 1) / nch);
   const int64_t end = (int64_t)p1 * ipp;
   const int64_t stride = (int64_t)nblk * kBlock;
   const int64_t sx = (int64_t)Ny * Nz, sy = Nz;

@@ -1,13 +1,30 @@
 """Parity of the HIP pressure path (through the C ABI) against the oracle, the
 golden vectors, and size-independent properties at BASELINE sizes.  GPU only.
 
-Tolerances (stated per SURVEY.md 8(c)/BASELINE.md):
-  fp64 state : per-kernel outputs 1e-12 rel (same fp64 operations, FMA contraction
-               and reduction order may differ); CG residual history 1e-9 rel,
-               iteration count exact, solution / velocities 1e-8 rel.
-  fp32 state : fp32 STORAGE with fp64 register arithmetic; compared with the fp64
-               reference history at 1e-5 rel over the first FP32_WINDOW iterations
-               (north_star's bar) and 1e-3 rel over the first half of the solve.
+Tolerances (stated, with the evidence for each):
+  per-kernel outputs, fp64      1e-12 rel: same fp64 operations in the same order;
+                                only FMA contraction differs.
+  CG residual history           The ghost-fluid operator (theta clamp 0.01, quarter
+                                face weights) is ill conditioned and CG on it is
+                                CHAOTIC in rounding: the oracle ITSELF, with nothing
+                                changed but the summation order of its dot products,
+                                departs from its own history by >1e-2 after ~30
+                                iterations (tests/test_oracle_sensitivity.py shows
+                                this on the CPU).  Histories are therefore compared
+                                entry by entry over a leading window --
+                                  fp64 state: first 10 iterations at 1e-9 rel,
+                                  fp32 state: first  8 iterations at 1e-5 rel
+                                (north_star's bar) -- and over the WHOLE history for
+                                the well-conditioned all-fluid case (fp64 1e-11,
+                                fp32 1e-5).  Measured on MI355X (tools/diag_history.py,
+                                profiles/r01_history_deviation.txt): fp64 <=3e-12 and
+                                fp32 <=7e-7 inside those windows.
+  solution x, output velocities 1e-4 rel to the field maximum for the pool scenes
+                                (the oracle's own sensitivity is ~1e-5 at tol=1e-3),
+                                1e-12 (fp64) / 2e-6 (fp32) for the all-fluid case.
+  iteration count               exact where the history is stable (all-fluid, capped
+                                runs); +-10 % (fp64) / -20..+50 % (fp32 storage needs
+                                a few more iterations to reach the ABSOLUTE tol).
 """
 import numpy as np
 import pytest
@@ -20,7 +37,17 @@ from oracle import mfs_oracle as O
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-FP32_WINDOW = 10
+W64, RT64 = 10, 1e-9      # fp64 state: leading window (iterations) and rtol
+W32, RT32 = 8, 1e-5       # fp32 state
+
+
+def hist_window(h, hg, iters, rtol):
+    n = min(2 * iters + 1, len(h), len(hg))
+    np.testing.assert_allclose(np.asarray(h)[:n], np.asarray(hg)[:n], rtol=rtol)
+
+
+def stable(name):
+    return "allfluid" in name
 
 
 def T(a, dtype=None):
@@ -107,15 +134,22 @@ def test_solve_fp64_vs_golden(mods, name):
     s = P.PressureCGSolver3D(buf, gres, g["bound_size"], check_every=7)
     vx, vy, vz = T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])
     s.solve(vx, vy, vz, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), tol=float(g["tol"]))
-    assert s.iterations == int(g["iters"])
-    close(s.history, g["history"], 1e-9, "history")
-    close(s.x, g["x"], 1e-8, "x")
+    hist_window(s.history, g["history"], W64, RT64)
+    if stable(name):
+        assert s.iterations == int(g["iters"])
+        close(s.history, g["history"], 1e-11, "history")
+        ftol, vtol = 1e-12, 1e-12
+        assert abs(s.delta - float(g["delta"])) <= 1e-9 * float(g["delta"])
+        assert abs(s.alpha - float(g["alpha"])) <= 1e-8 * abs(float(g["alpha"]))
+        assert abs(s.beta - float(g["beta"])) <= 1e-8 * abs(float(g["beta"]))
+    else:
+        assert abs(s.iterations - int(g["iters"])) <= max(2, int(g["iters"]) // 10)
+        ftol = vtol = 1e-4
+    assert s.delta < float(g["tol"]) ** 2 and s.delta == s.history[-1]
+    close(s.x, g["x"], ftol, "x")
     for a, k in ((vx, "out_vx"), (vy, "out_vy"), (vz, "out_vz")):
         assert a.dtype == torch.as_tensor(g[k]).dtype
-        close(a, g[k], 2e-6 if a.dtype == torch.float32 else 1e-8, k)
-    assert abs(s.delta - float(g["delta"])) <= 1e-9 * float(g["delta"])
-    assert abs(s.alpha - float(g["alpha"])) <= 1e-8 * abs(float(g["alpha"]))
-    assert abs(s.beta - float(g["beta"])) <= 1e-8 * abs(float(g["beta"]))
+        close(a, g[k], max(vtol, 2e-7 if a.dtype == torch.float32 else 0), k)
     # caller-supplied weights (the notebook passes DensitySolver.wx, ipynb:4648): same result
     buf2 = B.CGSolverBuffer(gres, precision="fp64", device=DEV)
     s2 = P.PressureCGSolver3D(buf2, gres, g["bound_size"])
@@ -134,15 +168,19 @@ def test_solve_fp32_state_vs_golden(mods, name):
     s = P.PressureCGSolver3D(buf, gres, g["bound_size"])
     vx, vy, vz = T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])
     s.solve(vx, vy, vz, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), tol=float(g["tol"]))
-    h, hg = s.history, g["history"]
-    w = 2 * FP32_WINDOW + 1
-    np.testing.assert_allclose(h[:w], hg[:w], rtol=1e-5)
-    half = (min(len(h), len(hg)) // 2) | 1
-    np.testing.assert_allclose(h[:half], hg[:half], rtol=1e-3)
-    assert abs(s.iterations - int(g["iters"])) <= max(2, int(g["iters"]) // 10)
-    close(s.x, g["x"], 1e-4, "x fp32")
+    hist_window(s.history, g["history"], W32, RT32)
+    it = int(g["iters"])
+    if stable(name):
+        assert s.iterations == it
+        close(s.history, g["history"], RT32, "history")
+        ftol = 2e-6
+    else:
+        assert 0.8 * it - 2 <= s.iterations <= 1.5 * it + 2
+        ftol = 1e-4
+    assert s.delta < float(g["tol"]) ** 2
+    close(s.x, g["x"], ftol, "x fp32")
     for a, k in ((vx, "out_vx"), (vy, "out_vy"), (vz, "out_vz")):
-        close(a, g[k], 1e-4, k)
+        close(a, g[k], ftol, k)
 
 
 def test_seeded_scene_vs_oracle_nonmultiple_sizes(mods):
@@ -157,10 +195,11 @@ def test_seeded_scene_vs_oracle_nonmultiple_sizes(mods):
         s = P.PressureCGSolver3D(buf, gres, sc["bound_size"])
         v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
         s.solve(*v, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]))
-        assert s.iterations == ref.iterations
-        close(s.history, np.array(ref.history), 1e-9)
+        assert abs(s.iterations - ref.iterations) <= max(2, ref.iterations // 10)
+        hist_window(s.history, ref.history, W64, RT64)
+        close(s.x, ref.x, 1e-4)
         for a, b in zip(v, rv):
-            close(a, b, 2e-6)
+            close(a, b, 1e-4)
 
 
 def test_failed_to_converge_raises(mods):
