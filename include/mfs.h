@@ -142,6 +142,13 @@ int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream);
 #define MFS_PCG_S_BETA 7
 #define MFS_PCG_S_LASTRR 8  /* r.r of the last completed iteration (what the reference keeps in self.delta) */
 void* mfs_pcg3d_scalars(mfs_pcg3d* h);
+/* performance knobs of the stencil kernel (results are identical for every setting):
+ * variant 0 = direct loads, 1 = x-marching in registers, 2 = x-marching + LDS-staged
+ * plane tiles (default); xchunk = cap on the planes of one march (0 = none);
+ * blocks_per_cu = workgroups per CU the (tile, plane) work is cut into;
+ * nontemporal > 0 marks the once-read coefficient streams, 0 never, < 0 = auto
+ * (on when the six arrays of one apply exceed the Infinity Cache).                */
+int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int nontemporal);
 
 #ifdef __cplusplus
 }

@@ -32,13 +32,13 @@
 #include <algorithm>
 
 #include "mfs_common.h"
+#include "mfs_pcg_apply.h"
 
 namespace mfs {
 
 constexpr int kBlock = 256;
 constexpr int kMaxPartials = 8192;
 constexpr int64_t kHistCap = 16384;
-constexpr int kNumXcd = 8;
 
 enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TOL2 = MFS_PCG_S_TOL2,
        S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
@@ -84,81 +84,8 @@ k_pcg_setup(int Nx, int Ny, int Nz, const void* lphi, int ldt, const void* wx, c
   diag[i] = (T)dg;
 }
 
-// ---------------------------------------------------------------- apply -----
 template <typename T, int VEC>
 __device__ __forceinline__ Vec<T, VEC> ldv(const T* p) { return *reinterpret_cast<const Vec<T, VEC>*>(p); }
-
-// Variant 0: direct loads, XCD-aware item order.  One work item = VEC consecutive
-// z cells of one interior (x,y) row.  Blocks with equal blockIdx%8 share an XCD
-// (and its 4 MiB L2): each label sweeps its own contiguous range of x planes so
-// the x+-1 / y+-1 re-reads of v, cx, cy are L2 hits and HBM sees each byte once.
-template <typename T, int VEC>
-__global__ void __launch_bounds__(kBlock)
-k_pcg_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag, const T* __restrict__ cx,
-            const T* __restrict__ cy, const T* __restrict__ cz, int Nx, int Ny, int Nz, int xb, int xe,
-            double* __restrict__ partial, const double* __restrict__ scal, int use_done) {
-  if (use_done && scal[S_DONE] != 0.0) return;
-  const int nzv = Nz / VEC;
-  const int ry = Ny - 2;
-  const int64_t ipp = (int64_t)ry * nzv;  // items per plane
-  const int np = xe - xb;
-  const int nch = min((int)gridDim.x, kNumXcd);  // plane chunks = XCD labels that own at least one block
-  const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
-  const int nblk = (gridDim.x - xcd + nch - 1) / nch;
-  const int p0 = (int)((int64_t)np * xcd / nch), p1 = (int)((int64_t)np * (xcd + 1) / nch);
-  const int64_t end = (int64_t)p1 * ipp;
-  const int64_t stride = (int64_t)nblk * kBlock;
-  const int64_t sx = (int64_t)Ny * Nz, sy = Nz;
-  double acc = 0.0;
-  for (int64_t it = (int64_t)p0 * ipp + (int64_t)slot * kBlock + threadIdx.x; it < end; it += stride) {
-    const int px = (int)(it / ipp);
-    const int rem = (int)(it - (int64_t)px * ipp);
-    const int yy = rem / nzv;
-    const int zv = rem - yy * nzv;
-    const int64_t base = (int64_t)(xb + px) * sx + (int64_t)(yy + 1) * sy + (int64_t)zv * VEC;
-    const Vec<T, VEC> vc = ldv<T, VEC>(v + base);
-    const Vec<T, VEC> vxp = ldv<T, VEC>(v + base + sx), vxm = ldv<T, VEC>(v + base - sx);
-    const Vec<T, VEC> vyp = ldv<T, VEC>(v + base + sy), vym = ldv<T, VEC>(v + base - sy);
-    const Vec<T, VEC> dg = ldv<T, VEC>(diag + base);
-    const Vec<T, VEC> cxm = ldv<T, VEC>(cx + base), cxp = ldv<T, VEC>(cx + base + sx);
-    const Vec<T, VEC> cym = ldv<T, VEC>(cy + base), cyp = ldv<T, VEC>(cy + base + sy);
-    const Vec<T, VEC> czm = ldv<T, VEC>(cz + base);
-    const bool first = zv == 0, last = zv == nzv - 1;
-    // z neighbours just outside the vector; never needed for the boundary cells z=0 / z=Nz-1
-    const double vzm = first ? 0.0 : (double)v[base - 1];
-    const double vzp = last ? 0.0 : (double)v[base + VEC];
-    const double czp_last = last ? 0.0 : (double)cz[base + VEC];
-    Vec<T, VEC> o;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const double zm = j == 0 ? vzm : (double)vc.v[j - 1];
-      const double zp = j == VEC - 1 ? vzp : (double)vc.v[j + 1];
-      const double czp = j == VEC - 1 ? czp_last : (double)czm.v[j + 1];
-      double val = 0.0;                                    // PressureCGSolver3D.py:65, order +x -x +y -y +z -z
-      val -= (double)cxp.v[j] * (double)vxp.v[j];
-      val -= (double)cxm.v[j] * (double)vxm.v[j];
-      val -= (double)cyp.v[j] * (double)vyp.v[j];
-      val -= (double)cym.v[j] * (double)vym.v[j];
-      val -= czp * zp;
-      val -= (double)czm.v[j] * zm;
-      val += (double)dg.v[j] * (double)vc.v[j];            // :128
-      o.v[j] = (T)val;
-      const bool bnd = (first && j == 0) || (last && j == VEC - 1);
-      if (!bnd) acc += (double)vc.v[j] * (double)o.v[j];
-    }
-    if (!first && !last) {
-      *reinterpret_cast<Vec<T, VEC>*>(out + base) = o;
-    } else {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const bool bnd = (first && j == 0) || (last && j == VEC - 1);
-        if (!bnd) out[base + j] = o.v[j];
-      }
-    }
-  }
-  const double tot = block_sum<kBlock>(acc);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
 
 // ---------------------------------------------------------- vector phases ---
 template <typename T, int VEC, typename F>
@@ -313,7 +240,8 @@ struct mfs_pcg3d {
   void *diag, *cx, *cy, *cz;
   void *b, *x, *d, *r, *q;
   int n_part_dq, n_part_rr;
-  int grid_apply, grid_vec;
+  int grid_apply, grid_vec, cus;
+  int variant, xchunk, nt, bpc;   // apply-kernel tuning (mfs_pcg3d_tune)
   bool vec_ok;
   bool is_setup;
   double* pinned;
@@ -330,27 +258,53 @@ static int env_int(const char* name, int defv) {
   return (s && *s) ? atoi(s) : defv;
 }
 
+template <typename T, int VEC>
+static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, double* partial, const double* done,
+                          hipStream_t st, int* grid_out) {
+  const T *dg = (const T*)h->diag, *cx = (const T*)h->cx, *cy = (const T*)h->cy, *cz = (const T*)h->cz;
+  const int nzv = h->Nz / VEC;
+  const int64_t ipp = (int64_t)(h->Ny - 2) * nzv;
+  int variant = h->variant;
+  const size_t lds = 2 * ((size_t)kApplyBlock * VEC + 2 * (size_t)h->Nz) * sizeof(T);
+  if (variant == 2 && lds > 64 * 1024) variant = 1;          // absurdly long rows: skip the LDS image
+  const int xchunk = std::max(0, h->xchunk);   // 0 = no cap on the length of one march
+  ApplyArgs a{h->Nx, h->Ny, h->Nz, xb, xe, xchunk};
+  if (variant == 0) {
+    const int64_t items = (int64_t)(xe - xb) * ipp;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->grid_apply, (items + kApplyBlock - 1) / kApplyBlock));
+    hipLaunchKernelGGL((k_pcg_apply_direct<T, VEC>), dim3(grid), dim3(kApplyBlock), 0, st, v, out, dg, cx, cy, cz, a,
+                       partial, done);
+    *grid_out = grid;
+  } else {
+    const int64_t tiles = (ipp + kApplyBlock - 1) / kApplyBlock;
+    const int64_t total = tiles * (xe - xb);                 // (tile, plane) pairs, cut into `grid` equal segments
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kMaxPartials, h->cus * h->bpc), total));
+    // Nontemporal loads for the once-read coefficient streams pay off only when the
+    // apply's working set (6 arrays) cannot sit in the 256 MiB Infinity Cache anyway;
+    // below that, default caching lets the next iteration hit on-die.  nt < 0 = auto.
+    const bool nt = h->nt < 0 ? (6.0 * (double)h->n * sizeof(T) > 200e6) : (h->nt != 0);
+    if (variant == 2) {
+      if (nt) hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, 1>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, a, partial, done);
+      else    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, 0>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, a, partial, done);
+    } else {
+      if (nt) hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, false, 1>), dim3(grid), dim3(kApplyBlock), 0, st, v, out, dg, cx, cy, cz, a, partial, done);
+      else    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, false, 0>), dim3(grid), dim3(kApplyBlock), 0, st, v, out, dg, cx, cy, cz, a, partial, done);
+    }
+    *grid_out = grid;
+  }
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
 template <typename T>
 static int launch_apply(mfs_pcg3d* h, const void* v, void* out, int xb, int xe, double* partial, int use_done,
                         hipStream_t st, int* grid_out) {
-  const int np = xe - xb;
-  if (np <= 0) { *grid_out = 0; return MFS_OK; }
+  if (xe - xb <= 0) { *grid_out = 0; return MFS_OK; }
   constexpr int VEC = VecOf<T>::N;
   const bool vec = h->vec_ok && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 16 == 0);
-  const int64_t items = (int64_t)np * (h->Ny - 2) * (vec ? h->Nz / VEC : h->Nz);
-  int grid = (int)std::min<int64_t>(h->grid_apply, (items + kBlock - 1) / kBlock);
-  grid = std::max(grid, 1);
-  if (vec)
-    hipLaunchKernelGGL((k_pcg_apply<T, VEC>), dim3(grid), dim3(kBlock), 0, st, (const T*)v, (T*)out,
-                       (const T*)h->diag, (const T*)h->cx, (const T*)h->cy, (const T*)h->cz, h->Nx, h->Ny, h->Nz, xb,
-                       xe, partial, h->scal, use_done);
-  else
-    hipLaunchKernelGGL((k_pcg_apply<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)v, (T*)out, (const T*)h->diag,
-                       (const T*)h->cx, (const T*)h->cy, (const T*)h->cz, h->Nx, h->Ny, h->Nz, xb, xe, partial,
-                       h->scal, use_done);
-  MFS_LAUNCH_CHECK();
-  *grid_out = grid;
-  return MFS_OK;
+  const double* done = use_done ? h->scal + S_DONE : nullptr;
+  if (vec) return launch_apply_v<T, VEC>(h, (const T*)v, (T*)out, xb, xe, partial, done, st, grid_out);
+  return launch_apply_v<T, 1>(h, (const T*)v, (T*)out, xb, xe, partial, done, st, grid_out);
 }
 
 static int apply_dispatch(mfs_pcg3d* h, const void* v, void* out, int64_t xb, int64_t xe, double* partial,
@@ -412,7 +366,12 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   }
-  h->grid_apply = std::min(kMaxPartials, cus * env_int("MFS_APPLY_BLOCKS_PER_CU", 8));
+  h->cus = cus;
+  h->variant = env_int("MFS_APPLY_VARIANT", 2);
+  h->xchunk = env_int("MFS_APPLY_XCHUNK", 0);
+  h->nt = env_int("MFS_APPLY_NT", -1);
+  h->bpc = env_int("MFS_APPLY_BLOCKS_PER_CU", 2);
+  h->grid_apply = std::min(kMaxPartials, cus * 8);
   h->grid_vec = std::min(kMaxPartials, cus * env_int("MFS_VEC_BLOCKS_PER_CU", 8));
   h->is_setup = false;
   h->pinned = nullptr;
@@ -478,10 +437,18 @@ int mfs_pcg3d_bind(mfs_pcg3d* h, void* b, void* x, void* d, void* r, void* q) {
 
 void* mfs_pcg3d_scalars(mfs_pcg3d* h) { return h ? h->scal : nullptr; }
 
+int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int nontemporal) {
+  MFS_REQUIRE(h, "null handle");
+  MFS_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0 (direct), 1 (march) or 2 (march + LDS)");
+  MFS_REQUIRE(xchunk >= 0 && blocks_per_cu >= 1, "xchunk must be >= 0 (0 = auto), blocks_per_cu >= 1");
+  h->variant = variant; h->xchunk = xchunk; h->nt = nontemporal; h->bpc = blocks_per_cu;
+  return MFS_OK;
+}
+
 int mfs_pcg3d_phase_apply(mfs_pcg3d* h, int64_t x_begin, int64_t x_end, int first, mfs_stream stream) {
   MFS_REQUIRE(h && h->d && h->is_setup, "engine not bound / set up");
   if (first) h->n_part_dq = 0;
-  MFS_REQUIRE(h->n_part_dq + h->grid_apply <= kMaxPartials, "too many apply ranges in one iteration");
+  MFS_REQUIRE(h->n_part_dq + std::max(h->grid_apply, h->cus * h->bpc) <= kMaxPartials, "too many apply ranges in one iteration");
   int grid = 0;
   if (int e = apply_dispatch(h, h->d, h->q, x_begin, x_end, h->part_dq + h->n_part_dq, 1, (hipStream_t)stream, &grid))
     return e;

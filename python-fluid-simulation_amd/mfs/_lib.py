@@ -64,6 +64,7 @@ SIGNATURES = {
     "mfs_pcg3d_begin_local": (_i, [_p, _d, _p]),
     "mfs_pcg3d_begin_finish": (_i, [_p, _p]),
     "mfs_pcg3d_scalars": (_p, [_p]),
+    "mfs_pcg3d_tune": (_i, [_p, _i, _i, _i, _i]),
 }
 
 _lib = None

@@ -42,6 +42,10 @@ class PcgEngine:
             except Exception:
                 pass
 
+    def tune(self, variant=2, xchunk=0, blocks_per_cu=2, nontemporal=-1):
+        _lib.check(self.lib.mfs_pcg3d_tune(self.h, int(variant), int(xchunk), int(blocks_per_cu), int(nontemporal)),
+                   "mfs_pcg3d_tune")
+
     # -- once per solve ------------------------------------------------------
     def setup(self, lphi, wx, wy, wz):
         g = self.gres
