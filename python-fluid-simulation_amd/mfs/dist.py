@@ -56,13 +56,14 @@ class SlabCG:
     all-reduces act on.  `d` is the local direction vector (planes 0 and L-1 are
     the ghost / boundary planes).  `dist` is torch.distributed or None (1 rank)."""
 
-    def __init__(self, ops, part, d, dist=None, group=None, overlap=True):
+    def __init__(self, ops, part, d, dist=None, group=None, overlap=True, force_multi=False):
         self.ops, self.part, self.d, self.dist, self.group = ops, part, d, dist, group
         self.overlap = overlap
         self.L = int(d.shape[0])
         if self.L != part.local_planes:
             raise ValueError("d does not match the partition's local plane count")
-        self.multi = dist is not None and part.world > 1
+        # force_multi: take the phase-by-phase path (with its collectives) even on one rank (tests)
+        self.multi = dist is not None and (part.world > 1 or force_multi)
 
     def _allreduce(self, slot):
         self.dist.all_reduce(self.ops.scalars[slot:slot + 1], group=self.group)
