@@ -191,10 +191,14 @@ def main():
             ms_b2b = s_ev.elapsed_time(e_ev) / reps
         achieved = alg_bytes / (ms_cg * 1e-3) / 1e9
         traffic = None
+        # HBM bytes per launch from PMC counters: collected by tools/pmc_bench.sh on this same command
+        # (separate rocprofv3 --pmc passes) and committed under profiles/; valid for the default workload only
         pj = os.path.join(REPO, "profiles", "r01_pmc_apply.json")
-        if os.path.exists(pj):
+        if os.path.exists(pj) and world == 1 and not args.force_phases:
             try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+                pm = json.load(open(pj))
+                if pm.get("workload") == f"{Nx}x{Ny}x{Nz} {args.dtype}":
+                    traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         rf = {"bound": "hbm", "kernel": "k_pcg_apply_march", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
