@@ -150,6 +150,59 @@ void* mfs_pcg3d_scalars(mfs_pcg3d* h);
  * (on when the six arrays of one apply exceed the Infinity Cache).                */
 int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int nontemporal);
 
+/* ------------------------------------------------------------------------- */
+/* Viscosity, 3D -- stateless kernels (the reference's module-level functions) */
+/* ------------------------------------------------------------------------- */
+/* replaces extrapolate -- solver/ViscosityCGSolver3D.py:8-39,472-502 (in place on vx,vy,vz;
+ * `workspace` holds the ping-pong copies and validity masks)                     */
+size_t mfs_visc_extrapolate3d_workspace_bytes(const int64_t gres[3], int v_dt);
+int mfs_visc_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
+                           const void* sphi, int sphi_dt, void* workspace, size_t workspace_bytes,
+                           mfs_stream stream);
+/* replaces initialize_solver -- solver/ViscosityCGSolver3D.py:41-246,504-513.
+ * `vol` is the doubled-grid fluid volume already divided by cell_vol/8 (self.vol, :568) */
+int mfs_visc_rhs3d(const int64_t gres[3], double scale, double mu,
+                   const void* vx, const void* vy, const void* vz, int v_dt,
+                   const void* sphi, int sphi_dt, const void* vol, int vol_dt,
+                   void* b_x, void* b_y, void* b_z, int b_dt, mfs_stream stream);
+/* replaces matvecmul -- solver/ViscosityCGSolver3D.py:248-456,515-524 */
+int mfs_visc_apply3d(const int64_t gres[3], double scale, double mu,
+                     const void* vx, const void* vy, const void* vz, int v_dt,
+                     void* out_x, void* out_y, void* out_z, int out_dt,
+                     const void* sphi, int sphi_dt, const void* vol, int vol_dt, mfs_stream stream);
+/* replaces apply_viscosity -- solver/ViscosityCGSolver3D.py:458-470,526-530 (in place on vx,vy,vz) */
+int mfs_visc_writeback3d(const int64_t gres[3], void* vx, void* vy, void* vz, int v_dt,
+                         const void* out_x, const void* out_y, const void* out_z, int out_dt,
+                         const void* sphi, int sphi_dt, mfs_stream stream);
+
+/* ------------------------------------------------------------------------- */
+/* Viscosity, 3D -- the CG engine (replaces the loop ViscosityCGSolver3D.py:575-612) */
+/* ------------------------------------------------------------------------- */
+/* The five CG vectors are FLAT arrays of mfs_vcg3d_dofs() elements laid out
+ * [ x-faces (Nx+1,Ny,Nz) | y-faces (Nx,Ny+1,Nz) | z-faces (Nx,Ny,Nz+1) ]; the
+ * reference's per-component arrays (x_x, x_y, x_z, ...) are views into them.       */
+typedef struct mfs_vcg3d mfs_vcg3d;
+size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt);
+int64_t mfs_vcg3d_dofs(const int64_t gres[3]);
+int mfs_vcg3d_create(mfs_vcg3d** out_host, const int64_t gres[3], int dt,
+                     void* workspace, size_t workspace_bytes, mfs_stream stream);
+int mfs_vcg3d_destroy(mfs_vcg3d* h);
+/* once per solve: de-interleave the doubled-grid `vol` into its 7 parity classes and
+ * `sphi >= 0` at the 3 face classes into byte masks (unit stride for the iteration) */
+int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int sphi_dt,
+                    const void* vol, int vol_dt, mfs_stream stream);
+/* out = A v on flat vectors; the per-iteration kernel(s) */
+int mfs_vcg3d_apply(mfs_vcg3d* h, const void* v, void* out, mfs_stream stream);
+int mfs_vcg3d_bind(mfs_vcg3d* h, void* b, void* x, void* d, void* r, void* q);
+/* q=A x (x = extrapolated velocity, NOT zeroed); d=r=b-q; delta0   (:575-587) */
+int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream);
+int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream);
+int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
+                   double* delta_host, double* alpha_host, double* beta_host);
+int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every,
+                    mfs_stream stream, int64_t* iters_host);
+int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,356 @@
+// mfs_cg_core.h -- the solver-independent part of the device-resident CG loop.
+//
+// Shared by the pressure engine (mfs_pcg.hip) and the viscosity engine
+// (mfs_visc.hip): the vector phases, the deterministic reductions, and the
+// device-resident control block.  The reference's loop is the same in both solvers
+// (solver/PressureCGSolver3D.py:198-223, solver/ViscosityCGSolver3D.py:575-612);
+// only `apply` differs.  One iteration:
+//
+//   <apply>          q = A d, per-block partials of d.q
+//   k_reduce(DQ)     1 block: partials -> scalars[DQ]        (+ DELTA <- RR)
+//   k_update_xr      x += a d ; r -= a q ; partials of r.r            6 scalars/DOF
+//   k_reduce(RR)     1 block: partials -> scalars[RR]
+//   k_update_d       convergence test, history, d = r + b d           3 scalars/DOF
+//
+// alpha, beta, delta, the iteration count and a `done` flag live in device
+// memory; once `done` is set every later kernel is a no-op, so the iteration
+// count and the final state equal the reference's even though the host only
+// looks every `check_every` iterations.  Reductions are deterministic: fixed
+// shuffle tree per wave, waves in order, blocks in order -- no float atomics.
+// Storage dtype T is fp32 or fp64; all arithmetic is fp64 in registers.
+#pragma once
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "mfs_common.h"
+
+namespace mfs {
+
+constexpr int kBlock = 256;
+constexpr int kMaxPartials = 8192;
+constexpr int64_t kHistCap = 16384;
+
+enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TOL2 = MFS_PCG_S_TOL2,
+       S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
+       S_LASTRR = MFS_PCG_S_LASTRR };
+
+
+template <typename T, int VEC>
+__device__ __forceinline__ Vec<T, VEC> ldv(const T* p) { return *reinterpret_cast<const Vec<T, VEC>*>(p); }
+
+// ---------------------------------------------------------- vector phases ---
+template <typename T, int VEC, typename F>
+__device__ __forceinline__ void for_each_vec(int64_t n, F&& f) {
+  // f(i, lanes): process elements [i, i+lanes)
+  const int64_t nv = n / VEC;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride) f(k * VEC, true);
+  // scalar tail (n % VEC elements) handled by the first threads of block 0
+  const int64_t tail = n - nv * VEC;
+  if (blockIdx.x == 0 && (int64_t)threadIdx.x < tail) f(nv * VEC + threadIdx.x, false);
+}
+
+// d = b - q ; r = d ; partial sum r^2          (PressureCGSolver3D.py:202-204)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_cg_init(const T* __restrict__ b, const T* __restrict__ q, T* __restrict__ d, T* __restrict__ r, int64_t n,
+          double* __restrict__ partial) {
+  double acc = 0.0;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      const Vec<T, VEC> bv = ldv<T, VEC>(b + i), qv = ldv<T, VEC>(q + i);
+      Vec<T, VEC> dv;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        dv.v[j] = (T)((double)bv.v[j] - (double)qv.v[j]);
+        acc += (double)dv.v[j] * (double)dv.v[j];
+      }
+      *reinterpret_cast<Vec<T, VEC>*>(d + i) = dv;
+      *reinterpret_cast<Vec<T, VEC>*>(r + i) = dv;
+    } else {
+      const T dv = (T)((double)b[i] - (double)q[i]);
+      d[i] = dv; r[i] = dv;
+      acc += (double)dv * (double)dv;
+    }
+  });
+  const double tot = block_sum<kBlock>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// alpha = delta / dq ; x += alpha d ; r -= alpha q ; partial sum r^2   (:211-216)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
+            const double* __restrict__ scal, double* __restrict__ partial) {
+  if (scal[S_DONE] != 0.0) return;
+  const double alpha = scal[S_DELTA] / scal[S_DQ];
+  double acc = 0.0;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      Vec<T, VEC> xv = ldv<T, VEC>(x + i), rv = ldv<T, VEC>(r + i);
+      const Vec<T, VEC> dv = ldv<T, VEC>(d + i), qv = ldv<T, VEC>(q + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        xv.v[j] = (T)((double)xv.v[j] + alpha * (double)dv.v[j]);
+        rv.v[j] = (T)((double)rv.v[j] - alpha * (double)qv.v[j]);
+        acc += (double)rv.v[j] * (double)rv.v[j];
+      }
+      *reinterpret_cast<Vec<T, VEC>*>(x + i) = xv;
+      *reinterpret_cast<Vec<T, VEC>*>(r + i) = rv;
+    } else {
+      const T xn = (T)((double)x[i] + alpha * (double)d[i]);
+      const T rn = (T)((double)r[i] - alpha * (double)q[i]);
+      x[i] = xn; r[i] = rn;
+      acc += (double)rn * (double)rn;
+    }
+  });
+  const double tot = block_sum<kBlock>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// convergence test (:218), bookkeeping, beta (:220), d = r + beta d (:221)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __restrict__ scal,
+           double* __restrict__ hist, int64_t hist_cap) {
+  if (scal[S_DONE] != 0.0) return;
+  const double rr = scal[S_RR], delta = scal[S_DELTA], tol2 = scal[S_TOL2];
+  const bool conv = rr < tol2;
+  const double beta = rr / delta;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double dq = scal[S_DQ];
+    const int64_t it = (int64_t)scal[S_ITERS];
+    if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+    scal[S_ITERS] = (double)(it + 1);
+    scal[S_LASTRR] = rr;
+    scal[S_ALPHA] = delta / dq;
+    if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
+  }
+  if (conv) return;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      Vec<T, VEC> dv = ldv<T, VEC>(d + i);
+      const Vec<T, VEC> rv = ldv<T, VEC>(r + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dv.v[j] = (T)((double)rv.v[j] + beta * (double)dv.v[j]);
+      *reinterpret_cast<Vec<T, VEC>*>(d + i) = dv;
+    } else {
+      d[i] = (T)((double)r[i] + beta * (double)d[i]);
+    }
+  });
+}
+
+// x *= 0.0 (:198) -- a multiply, not a memset, so NaN/inf survive as in the reference.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_scale0(T* __restrict__ x, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = (T)((double)x[i] * 0.0);
+}
+
+// one block: partials[0..count) -> scal[which]; fixed order => deterministic.
+static __global__ void __launch_bounds__(kBlock)
+k_reduce(const double* __restrict__ partial, int count, double* __restrict__ scal, int which, int check_done) {
+  if (check_done && scal[S_DONE] != 0.0) return;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) acc += partial[i];
+  const double tot = block_sum<kBlock>(acc);
+  if (threadIdx.x == 0) {
+    scal[which] = tot;
+    if (which == S_DQ) scal[S_DELTA] = scal[S_RR];  // the iteration that starts here begins from the latest r.r
+  }
+}
+
+static __global__ void k_begin_init(double* scal, double tol2) {
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < MFS_PCG_NSCALARS; ++i) scal[i] = 0.0;
+    scal[S_TOL2] = tol2;
+  }
+}
+
+static __global__ void k_begin_finish(double* scal, double* hist) {
+  if (threadIdx.x == 0) {
+    const double rr = scal[S_RR];
+    scal[S_DELTA] = rr;
+    scal[S_LASTRR] = rr;
+    hist[0] = rr;
+    if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0;  // `if not self.delta < tol ** 2` (:206)
+  }
+}
+
+
+// ------------------------------------------------------------- host side ----
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static inline int env_int(const char* name, int defv) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : defv;
+}
+
+// The flat CG state of one engine: n DOFs of dtype dt in five caller-owned vectors.
+struct CgCore {
+  int dt = MFS_F64;
+  int64_t n = 0;
+  size_t elt = 8;
+  double *scal = nullptr, *hist = nullptr, *part_dq = nullptr, *part_rr = nullptr;
+  void *b = nullptr, *x = nullptr, *d = nullptr, *r = nullptr, *q = nullptr;
+  int n_part_dq = 0, n_part_rr = 0;
+  int grid_vec = 2048, cus = 256;
+  double* pinned = nullptr;
+};
+
+static inline size_t core_ws_bytes() {
+  return 256 + align_up((size_t)kHistCap * 8, 256) + 2 * align_up((size_t)kMaxPartials * 8, 256);
+}
+
+// carve scalars / history / partials out of the head of the workspace; returns the first free byte
+static inline char* core_carve(CgCore& c, char* p) {
+  c.scal = (double*)p; p += 256;
+  c.hist = (double*)p; p += align_up((size_t)kHistCap * 8, 256);
+  c.part_dq = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
+  c.part_rr = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
+  return p;
+}
+
+static inline int core_init(CgCore& c, int dt, int64_t n) {
+  c.dt = dt; c.n = n; c.elt = dtype_size(dt);
+  int dev = 0;
+  c.cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c.cus = prop.multiProcessorCount;
+  }
+  c.grid_vec = std::min(kMaxPartials, c.cus * env_int("MFS_VEC_BLOCKS_PER_CU", 8));
+  if (hipHostMalloc((void**)&c.pinned, MFS_PCG_NSCALARS * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc for the poll buffer failed");
+    return MFS_E_HIP;
+  }
+  return MFS_OK;
+}
+
+static inline void core_free(CgCore& c) {
+  if (c.pinned) (void)hipHostFree(c.pinned);
+  c.pinned = nullptr;
+}
+
+static inline int core_bind(CgCore& c, void* b, void* x, void* d, void* r, void* q) {
+  MFS_REQUIRE(b && x && d && r && q, "null CG vector");
+  void* a[5] = {b, x, d, r, q};
+  for (int i = 0; i < 5; ++i) {
+    MFS_REQUIRE(((uintptr_t)a[i] % c.elt) == 0, "CG vector not aligned to its element size");
+    for (int j = i + 1; j < 5; ++j) MFS_REQUIRE(a[i] != a[j], "CG vectors must be distinct arrays");
+  }
+  c.b = b; c.x = x; c.d = d; c.r = r; c.q = q;
+  return MFS_OK;
+}
+
+static inline bool core_vec_ok(const CgCore& c) {
+  auto al = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+  return al(c.b) && al(c.x) && al(c.d) && al(c.r) && al(c.q);
+}
+
+static inline int core_vec_grid(const CgCore& c, bool vec) {
+  const int64_t per = vec ? (c.dt == MFS_F32 ? 4 : 2) : 1;
+  return std::max(1, (int)std::min<int64_t>(c.grid_vec, (c.n / per + kBlock - 1) / kBlock));
+}
+
+static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st, which == 0 ? c.part_dq : c.part_rr,
+                     which == 0 ? c.n_part_dq : c.n_part_rr, c.scal, which == 0 ? S_DQ : S_RR, check_done);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+static inline int core_update_xr(CgCore& c, hipStream_t st) {
+  MFS_REQUIRE(c.x, "engine not bound");
+  const bool vec = core_vec_ok(c);
+  const int grid = core_vec_grid(c, vec);
+  if (c.dt == MFS_F32) {
+    if (vec) hipLaunchKernelGGL((k_update_xr<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)c.x, (const float*)c.d, (float*)c.r, (const float*)c.q, c.n, c.scal, c.part_rr);
+    else hipLaunchKernelGGL((k_update_xr<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)c.x, (const float*)c.d, (float*)c.r, (const float*)c.q, c.n, c.scal, c.part_rr);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_update_xr<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)c.x, (const double*)c.d, (double*)c.r, (const double*)c.q, c.n, c.scal, c.part_rr);
+    else hipLaunchKernelGGL((k_update_xr<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)c.x, (const double*)c.d, (double*)c.r, (const double*)c.q, c.n, c.scal, c.part_rr);
+  }
+  MFS_LAUNCH_CHECK();
+  c.n_part_rr = grid;
+  return MFS_OK;
+}
+
+static inline int core_update_d(CgCore& c, hipStream_t st) {
+  MFS_REQUIRE(c.d, "engine not bound");
+  const bool vec = core_vec_ok(c);
+  const int grid = core_vec_grid(c, vec);
+  if (c.dt == MFS_F32) {
+    if (vec) hipLaunchKernelGGL((k_update_d<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap);
+    else hipLaunchKernelGGL((k_update_d<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_update_d<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)c.d, (const double*)c.r, c.n, c.scal, c.hist, kHistCap);
+    else hipLaunchKernelGGL((k_update_d<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)c.d, (const double*)c.r, c.n, c.scal, c.hist, kHistCap);
+  }
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+// begin, part 1: scalars <- 0, tol^2; x *= 0 (only if zero_x: the pressure solver's `self.x *= 0.0`)
+static inline int core_begin_pre(CgCore& c, double tol, bool zero_x, hipStream_t st) {
+  MFS_REQUIRE(c.x, "engine not bound");
+  hipLaunchKernelGGL(k_begin_init, dim3(1), dim3(64), 0, st, c.scal, tol * tol);
+  MFS_LAUNCH_CHECK();
+  if (zero_x) {
+    const int gs = std::max(1, (int)std::min<int64_t>(c.grid_vec, (c.n + kBlock - 1) / kBlock));
+    if (c.dt == MFS_F32) hipLaunchKernelGGL((k_scale0<float>), dim3(gs), dim3(kBlock), 0, st, (float*)c.x, c.n);
+    else hipLaunchKernelGGL((k_scale0<double>), dim3(gs), dim3(kBlock), 0, st, (double*)c.x, c.n);
+    MFS_LAUNCH_CHECK();
+  }
+  return MFS_OK;
+}
+
+// begin, part 2 (after q = A x): d = r = b - q, partial r.r, reduce -> scalars[RR]
+static inline int core_begin_post(CgCore& c, hipStream_t st) {
+  const bool vec = core_vec_ok(c);
+  const int g2 = core_vec_grid(c, vec);
+  if (c.dt == MFS_F32) {
+    if (vec) hipLaunchKernelGGL((k_cg_init<float, 4>), dim3(g2), dim3(kBlock), 0, st, (const float*)c.b, (const float*)c.q, (float*)c.d, (float*)c.r, c.n, c.part_rr);
+    else hipLaunchKernelGGL((k_cg_init<float, 1>), dim3(g2), dim3(kBlock), 0, st, (const float*)c.b, (const float*)c.q, (float*)c.d, (float*)c.r, c.n, c.part_rr);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_cg_init<double, 2>), dim3(g2), dim3(kBlock), 0, st, (const double*)c.b, (const double*)c.q, (double*)c.d, (double*)c.r, c.n, c.part_rr);
+    else hipLaunchKernelGGL((k_cg_init<double, 1>), dim3(g2), dim3(kBlock), 0, st, (const double*)c.b, (const double*)c.q, (double*)c.d, (double*)c.r, c.n, c.part_rr);
+  }
+  MFS_LAUNCH_CHECK();
+  c.n_part_rr = g2;
+  return core_reduce(c, 1, 0, st);
+}
+
+static inline int core_begin_finish(CgCore& c, hipStream_t st) {
+  hipLaunchKernelGGL(k_begin_finish, dim3(1), dim3(64), 0, st, c.scal, c.hist);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+static inline int core_poll(CgCore& c, hipStream_t st, int64_t* iters, int* done, double* delta, double* alpha,
+                            double* beta) {
+  MFS_HIP_TRY(hipMemcpyAsync(c.pinned, c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
+  MFS_HIP_TRY(hipStreamSynchronize(st));
+  if (iters) *iters = (int64_t)c.pinned[S_ITERS];
+  if (done) *done = c.pinned[S_DONE] != 0.0;
+  if (delta) *delta = c.pinned[S_LASTRR];
+  if (alpha) *alpha = c.pinned[S_ALPHA];
+  if (beta) *beta = c.pinned[S_BETA];
+  return MFS_OK;
+}
+
+static inline int64_t core_history(CgCore& c, double* out_host, int64_t cap, hipStream_t st) {
+  if (!out_host || cap < 0) { set_error("history: bad argument"); return MFS_E_INVALID; }
+  if (hipMemcpyAsync(c.pinned, c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) { set_error("history: scalar readback failed"); return MFS_E_HIP; }
+  int64_t cnt = std::min<int64_t>(2 * (int64_t)c.pinned[S_ITERS] + 1, kHistCap);
+  cnt = std::min(cnt, cap);
+  if (cnt > 0) {
+    if (hipMemcpyAsync(out_host, c.hist, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { set_error("history: copy failed"); return MFS_E_HIP; }
+  }
+  return cnt;
+}
+
+}  // namespace mfs

@@ -1,0 +1,566 @@
+// mfs_visc.hip -- ViscosityCGSolver3D on gfx950: the variational-viscosity operator
+// (3 coupled face components, 15 taps per row), its RHS, the 3-sweep extrapolation,
+// the write-back, and the CG engine around them.
+//
+// Reference: solver/ViscosityCGSolver3D.py.  Rows (u,v,w) are described by ONE tap
+// table (kTaps below; SURVEY.md Appendix A, re-read against :248-456) from which
+// both the operator (mask `sphi >= 0`, sign as listed) and the RHS (mask `sphi < 0`,
+// opposite sign, :41-246) are instantiated -- the same table drives the oracle.
+//
+// Two forms of the operator:
+//  * k_visc_row_direct: straight from the caller's doubled-grid `sphi` / `vol`
+//    arrays (stride-2 reads).  Used for the module-level drop-ins `matvecmul` /
+//    `initialize_solver` and once per solve for the RHS.
+//  * k_vcg_apply: the per-iteration kernel.  Once per solve k_vcg_setup
+//    de-interleaves `vol` into its 7 used parity classes (cell centres, 3 face
+//    classes, 3 edge classes) and `sphi >= 0` at the 3 face
+//    classes into byte masks, all unit-stride.  A tap's mask sample is always the
+//    validity of the tapped face itself, so the masks are per-DOF bytes.
+//    Algorithmic traffic: 3 (v) + 7 (vol classes) + 3 (out) scalars + 3 mask bytes
+//    per cell, vs 8x-strided reads of two (2N+1)^3 arrays in the reference.
+#include "mfs_cg_core.h"
+
+namespace mfs {
+
+struct VTap { int fac, vol, sgn, comp, dx, dy, dz, mx, my, mz; };
+// vol sample index: 0=c 1=R 2=L 3=T 4=B 5=F 6=K   (offsets from the face's doubled index D)
+__device__ constexpr int kVolOff[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+// D = 2*(x,y,z) + kD0[row]
+__device__ constexpr int kD0[3][3] = {{0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
+// diag = c + k*(fR*R + fL*L + fT*T + fB*B + fF*F + fK*K)    (:268, :338, :408)
+__device__ constexpr int kDiagFac[3][6] = {{2, 2, 1, 1, 1, 1}, {1, 1, 2, 2, 1, 1}, {1, 1, 1, 1, 2, 2}};
+__device__ constexpr VTap kTaps[3][14] = {
+    {  // u-row :271-314
+        {2, 1, -1, 0, 1, 0, 0, 2, 0, 0},   {2, 2, -1, 0, -1, 0, 0, -2, 0, 0}, {1, 3, -1, 0, 0, 1, 0, 0, 2, 0},
+        {1, 4, -1, 0, 0, -1, 0, 0, -2, 0}, {1, 5, -1, 0, 0, 0, 1, 0, 0, 2},   {1, 6, -1, 0, 0, 0, -1, 0, 0, -2},
+        {1, 3, -1, 1, 0, 1, 0, 1, 1, 0},   {1, 3, +1, 1, -1, 1, 0, -1, 1, 0}, {1, 4, +1, 1, 0, 0, 0, 1, -1, 0},
+        {1, 4, -1, 1, -1, 0, 0, -1, -1, 0}, {1, 5, -1, 2, 0, 0, 1, 1, 0, 1},  {1, 5, +1, 2, -1, 0, 1, -1, 0, 1},
+        {1, 6, +1, 2, 0, 0, 0, 1, 0, -1},  {1, 6, -1, 2, -1, 0, 0, -1, 0, -1},
+    },
+    {  // v-row :341-384
+        {1, 1, -1, 1, 1, 0, 0, 2, 0, 0},   {1, 2, -1, 1, -1, 0, 0, -2, 0, 0}, {2, 3, -1, 1, 0, 1, 0, 0, 2, 0},
+        {2, 4, -1, 1, 0, -1, 0, 0, -2, 0}, {1, 5, -1, 1, 0, 0, 1, 0, 0, 2},   {1, 6, -1, 1, 0, 0, -1, 0, 0, -2},
+        {1, 1, -1, 0, 1, 0, 0, 1, 1, 0},   {1, 1, +1, 0, 1, -1, 0, 1, -1, 0}, {1, 2, +1, 0, 0, 0, 0, -1, 1, 0},
+        {1, 2, -1, 0, 0, -1, 0, -1, -1, 0}, {1, 5, -1, 2, 0, 0, 1, 0, 1, 1},  {1, 5, +1, 2, 0, -1, 1, 0, -1, 1},
+        {1, 6, +1, 2, 0, 0, 0, 0, 1, -1},  {1, 6, -1, 2, 0, -1, 0, 0, -1, -1},
+    },
+    {  // w-row :411-454
+        {1, 1, -1, 2, 1, 0, 0, 2, 0, 0},   {1, 2, -1, 2, -1, 0, 0, -2, 0, 0}, {1, 3, -1, 2, 0, 1, 0, 0, 2, 0},
+        {1, 4, -1, 2, 0, -1, 0, 0, -2, 0}, {2, 5, -1, 2, 0, 0, 1, 0, 0, 2},   {2, 6, -1, 2, 0, 0, -1, 0, 0, -2},
+        {1, 1, -1, 0, 1, 0, 0, 1, 0, 1},   {1, 1, +1, 0, 1, 0, -1, 1, 0, -1}, {1, 2, +1, 0, 0, 0, 0, -1, 0, 1},
+        {1, 2, -1, 0, 0, 0, -1, -1, 0, -1}, {1, 3, -1, 1, 0, 1, 0, 0, 1, 1},  {1, 3, +1, 1, 0, 1, -1, 0, 1, -1},
+        {1, 4, +1, 1, 0, 0, 0, 0, -1, 1},  {1, 4, -1, 1, 0, 0, -1, 0, -1, -1},
+    },
+};
+
+struct G3 {
+  int N[3];
+  __host__ __device__ int sh(int comp, int ax) const { return N[ax] + (comp == ax ? 1 : 0); }
+  __host__ __device__ int64_t nface(int comp) const { return (int64_t)sh(comp, 0) * sh(comp, 1) * sh(comp, 2); }
+  __device__ int64_t fidx(int comp, int x, int y, int z) const {
+    return ((int64_t)x * sh(comp, 1) + y) * sh(comp, 2) + z;
+  }
+  __device__ int64_t dg(int i, int j, int k) const { return ((int64_t)i * (2 * N[1] + 1) + j) * (2 * N[2] + 1) + k; }
+};
+
+struct V3 { const void* p[3]; };
+struct W3 { void* p[3]; };
+
+// ----------------------------------------------------- direct (doubled grid) --
+template <int AXIS, bool RHS>
+__global__ void __launch_bounds__(256)
+k_visc_row_direct(G3 g, double scale, double mu, V3 v, int vdt, void* out, int odt, const void* sphi, int sdt,
+                  const void* vol, int voldt) {
+  const int s1 = g.sh(AXIS, 1), s2 = g.sh(AXIS, 2), s0 = g.sh(AXIS, 0);
+  const int64_t n = (int64_t)s0 * s1 * s2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int z = (int)(i % s2), y = (int)((i / s2) % s1), x = (int)(i / ((int64_t)s2 * s1));
+  if (x == 0 || x >= s0 - 1 || y == 0 || y >= s1 - 1 || z == 0 || z >= s2 - 1) return;   // array-boundary faces untouched
+  const int Dx = 2 * x + kD0[AXIS][0], Dy = 2 * y + kD0[AXIS][1], Dz = 2 * z + kD0[AXIS][2];
+  if (ldx(sphi, sdt, g.dg(Dx, Dy, Dz)) < 0) { stx(out, odt, i, 0.0); return; }            // solid face
+  double vs[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) vs[k] = ldx(vol, voldt, g.dg(Dx + kVolOff[k][0], Dy + kVolOff[k][1], Dz + kVolOff[k][2]));
+  const double own = ldx(v.p[AXIS], vdt, i);
+  double val;
+  if (RHS) {
+    val = own * vs[0];
+  } else {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double t = kDiagFac[AXIS][k] == 2 ? 2 * vs[k + 1] : vs[k + 1];
+      s = k == 0 ? t : s + t;
+    }
+    val = (vs[0] + scale * mu * s) * own;
+  }
+#pragma unroll
+  for (int t = 0; t < 14; ++t) {
+    const VTap tp = kTaps[AXIS][t];
+    const double k = tp.fac == 2 ? 2 * scale * mu : scale * mu;
+    const double term = k * vs[tp.vol] * ldx(v.p[tp.comp], vdt, g.fidx(tp.comp, x + tp.dx, y + tp.dy, z + tp.dz));
+    const double m = ldx(sphi, sdt, g.dg(Dx + tp.mx, Dy + tp.my, Dz + tp.mz));
+    if (RHS) { if (m < 0) val -= tp.sgn * term; }
+    else     { if (m >= 0) val += tp.sgn * term; }
+  }
+  stx(out, odt, i, val);
+}
+
+// ------------------------------------------------------------ extrapolation --
+// valid = sphi(face) >= 0 for every face of the component (:479-481)
+template <int AXIS>
+__global__ void __launch_bounds__(256) k_visc_valid(G3 g, const void* sphi, int sdt, unsigned char* valid) {
+  const int s1 = g.sh(AXIS, 1), s2 = g.sh(AXIS, 2);
+  const int64_t n = g.nface(AXIS);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int z = (int)(i % s2), y = (int)((i / s2) % s1), x = (int)(i / ((int64_t)s2 * s1));
+  valid[i] = ldx(sphi, sdt, g.dg(2 * x + kD0[AXIS][0], 2 * y + kD0[AXIS][1], 2 * z + kD0[AXIS][2])) >= 0 ? 1 : 0;
+}
+
+// one Jacobi sweep (:8-39): every face is written (copy-through or new value), so
+// the in/out buffers ping-pong exactly like the reference's new_v / new_valid copies.
+__global__ void __launch_bounds__(256)
+k_visc_extrap_sweep(int s0, int s1, int s2, const void* vin, void* vout, int vdt, const unsigned char* valid_in,
+                    unsigned char* valid_out) {
+  const int64_t n = (int64_t)s0 * s1 * s2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int z = (int)(i % s2), y = (int)((i / s2) % s1), x = (int)(i / ((int64_t)s2 * s1));
+  double nv = ldx(vin, vdt, i);
+  unsigned char va = valid_in[i];
+  const bool interior = !(x == 0 || x >= s0 - 1 || y == 0 || y >= s1 - 1 || z == 0 || z >= s2 - 1);
+  if (interior && !va) {
+    double val = 0.0;
+    int count = 0;
+    const int64_t sx = (int64_t)s1 * s2, sy = s2;
+    const int64_t nb[6] = {i + sx, i - sx, i + sy, i - sy, i + 1, i - 1};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (valid_in[nb[k]]) { val += ldx(vin, vdt, nb[k]); ++count; }
+    if (count > 0) { nv = val / count; va = 1; }
+  }
+  stx(vout, vdt, i, nv);
+  valid_out[i] = va;
+}
+
+// apply_viscosity_kernel (:458-470): x,y,z in [1, N-1]
+__global__ void __launch_bounds__(256)
+k_visc_writeback(G3 g, W3 v, int vdt, V3 o, int odt, const void* sphi, int sdt) {
+  const int64_t n = (int64_t)g.N[0] * g.N[1] * g.N[2];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int z = (int)(i % g.N[2]), y = (int)((i / g.N[2]) % g.N[1]), x = (int)(i / ((int64_t)g.N[2] * g.N[1]));
+  if (x == 0 || y == 0 || z == 0) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (ldx(sphi, sdt, g.dg(2 * x + kD0[c][0], 2 * y + kD0[c][1], 2 * z + kD0[c][2])) >= 0) {
+      const int64_t f = g.fidx(c, x, y, z);
+      stx(v.p[c], vdt, f, ldx(o.p[c], odt, f));
+    }
+  }
+}
+
+// ------------------------------------------------------------ compact form ---
+// parity class code p = (i&1)<<2 | (j&1)<<1 | (k&1) of a doubled-grid node;
+// class array dims: odd axis -> N, even axis -> N+1; compact index = node >> 1.
+struct Compact {
+  const void* vol[8];           // state dtype; [0] (e,e,e) unused
+  const unsigned char* msk[8];  // only the three face classes 3 (e,o,o), 5 (o,e,o), 6 (o,o,e)
+  int N[3];
+  __host__ __device__ int dim(int p, int ax) const { return N[ax] + (((p >> (2 - ax)) & 1) ? 0 : 1); }
+  __host__ __device__ int64_t count(int p) const { return (int64_t)dim(p, 0) * dim(p, 1) * dim(p, 2); }
+};
+__host__ __device__ constexpr int face_class(int comp) { return comp == 0 ? 3 : (comp == 1 ? 5 : 6); }
+__host__ __device__ constexpr int fdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_vcg_setup(int Nx, int Ny, int Nz, const void* sphi, int sdt, const void* vol, int voldt, T* o1, T* o2, T* o3, T* o4,
+            T* o5, T* o6, T* o7, unsigned char* m3, unsigned char* m5, unsigned char* m6) {
+  const int d1 = 2 * Ny + 1, d2 = 2 * Nz + 1;
+  const int64_t n = (int64_t)(2 * Nx + 1) * d1 * d2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = (int)(i % d2), j = (int)((i / d2) % d1), ii = (int)(i / ((int64_t)d2 * d1));
+  const int p = ((ii & 1) << 2) | ((j & 1) << 1) | (k & 1);
+  if (p == 0) return;
+  const int e1 = Ny + ((j & 1) ? 0 : 1), e2 = Nz + ((k & 1) ? 0 : 1);
+  const int64_t ci = ((int64_t)(ii >> 1) * e1 + (j >> 1)) * e2 + (k >> 1);
+  T* dst = p == 1 ? o1 : p == 2 ? o2 : p == 3 ? o3 : p == 4 ? o4 : p == 5 ? o5 : p == 6 ? o6 : o7;
+  dst[ci] = (T)ldx(vol, voldt, i);
+  if (p == 3 || p == 5 || p == 6) {
+    unsigned char* m = p == 3 ? m3 : (p == 5 ? m5 : m6);
+    m[ci] = ldx(sphi, sdt, i) >= 0 ? 1 : 0;
+  }
+}
+
+template <typename T>
+struct Vec3T { const T* p[3]; };
+
+// per-iteration operator row on the compact arrays; also d.q partials.
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(256)
+k_vcg_apply(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ out, double* __restrict__ partial,
+            const double* __restrict__ done_flag) {
+  if (done_flag && *done_flag != 0.0) return;
+  const int s0 = c.N[0] + (AXIS == 0), s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
+  const int i0 = s0 - 2, i1 = s1 - 2, i2 = s2 - 2;                       // interior extents
+  const int64_t nint = (int64_t)i0 * i1 * i2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const unsigned char* own_mask = c.msk[face_class(AXIS)];
+  double acc = 0.0;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nint; it += stride) {
+    const int z = 1 + (int)(it % i2), y = 1 + (int)((it / i2) % i1), x = 1 + (int)(it / ((int64_t)i2 * i1));
+    const int64_t f = ((int64_t)x * s1 + y) * s2 + z;
+    double val = 0.0;
+    if (own_mask[f]) {
+      double vs[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int ax = kD0[AXIS][0] + kVolOff[k][0], ay = kD0[AXIS][1] + kVolOff[k][1], az = kD0[AXIS][2] + kVolOff[k][2];
+        const int p = ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1);
+        const int e1 = c.N[1] + ((ay & 1) ? 0 : 1), e2 = c.N[2] + ((az & 1) ? 0 : 1);
+        vs[k] = (double)((const T*)c.vol[p])[((int64_t)(x + fdiv2(ax)) * e1 + (y + fdiv2(ay))) * e2 + (z + fdiv2(az))];
+      }
+      const double own = (double)v.p[AXIS][f];
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double t = kDiagFac[AXIS][k] == 2 ? 2 * vs[k + 1] : vs[k + 1];
+        s = k == 0 ? t : s + t;
+      }
+      val = (vs[0] + k1 * s) * own;
+#pragma unroll
+      for (int t = 0; t < 14; ++t) {
+        const VTap tp = kTaps[AXIS][t];
+        const int cs1 = c.N[1] + (tp.comp == 1), cs2 = c.N[2] + (tp.comp == 2);
+        const int64_t nb = ((int64_t)(x + tp.dx) * cs1 + (y + tp.dy)) * cs2 + (z + tp.dz);
+        // the tap's mask sample is the validity of the tapped face itself (see header)
+        if (c.msk[face_class(tp.comp)][nb]) {
+          const double term = (tp.fac == 2 ? k2 : k1) * vs[tp.vol] * (double)v.p[tp.comp][nb];
+          val += tp.sgn * term;
+        }
+      }
+      acc += own * (double)(T)val;
+    }
+    out[f] = (T)val;
+  }
+  const double tot = block_sum<256>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+}  // namespace mfs
+
+using namespace mfs;
+
+struct mfs_vcg3d {
+  G3 g;
+  int dt;
+  int64_t nf[3], off[3], n;
+  CgCore c;
+  char* ws;
+  size_t ws_bytes;
+  Compact cp;
+  double k1, k2;
+  bool is_setup;
+  int grid_row;
+};
+
+static int64_t class_count(const int64_t gres[3], int p) {
+  int64_t n = 1;
+  for (int ax = 0; ax < 3; ++ax) n *= gres[ax] + (((p >> (2 - ax)) & 1) ? 0 : 1);
+  return n;
+}
+
+static int check_gres(const int64_t gres[3]) {
+  MFS_REQUIRE(gres != nullptr, "gres is null");
+  for (int a = 0; a < 3; ++a) MFS_REQUIRE(gres[a] >= 1 && gres[a] <= 2048, "grid resolution out of range [1,2048]");
+  return MFS_OK;
+}
+
+static G3 make_g(const int64_t gres[3]) {
+  G3 g;
+  for (int a = 0; a < 3; ++a) g.N[a] = (int)gres[a];
+  return g;
+}
+
+template <bool RHS>
+static int launch_rows_direct(const int64_t gres[3], double scale, double mu, const void* vx, const void* vy,
+                              const void* vz, int v_dt, void* ox, void* oy, void* oz, int o_dt, const void* sphi,
+                              int sphi_dt, const void* vol, int vol_dt, hipStream_t st) {
+  if (int e = check_gres(gres)) return e;
+  MFS_REQUIRE(vx && vy && vz && ox && oy && oz && sphi && vol, "null array");
+  MFS_REQUIRE(dtype_ok(v_dt) && dtype_ok(o_dt) && dtype_ok(sphi_dt) && dtype_ok(vol_dt), "dtype");
+  G3 g = make_g(gres);
+  V3 v{{vx, vy, vz}};
+  hipLaunchKernelGGL((k_visc_row_direct<0, RHS>), dim3(cdiv(g.nface(0), 256)), dim3(256), 0, st, g, scale, mu, v, v_dt,
+                     ox, o_dt, sphi, sphi_dt, vol, vol_dt);
+  hipLaunchKernelGGL((k_visc_row_direct<1, RHS>), dim3(cdiv(g.nface(1), 256)), dim3(256), 0, st, g, scale, mu, v, v_dt,
+                     oy, o_dt, sphi, sphi_dt, vol, vol_dt);
+  hipLaunchKernelGGL((k_visc_row_direct<2, RHS>), dim3(cdiv(g.nface(2), 256)), dim3(256), 0, st, g, scale, mu, v, v_dt,
+                     oz, o_dt, sphi, sphi_dt, vol, vol_dt);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+template <typename T>
+static int vcg_apply_T(mfs_vcg3d* h, const void* v, void* out, double* partial, const double* done, hipStream_t st,
+                       int* nparts) {
+  const T* vb = (const T*)v;
+  T* ob = (T*)out;
+  Vec3T<T> vv{{vb + h->off[0], vb + h->off[1], vb + h->off[2]}};
+  int used = 0;
+  auto grid_for = [&](int ax) {
+    const int64_t nint = (int64_t)(h->g.sh(ax, 0) - 2) * (h->g.sh(ax, 1) - 2) * (h->g.sh(ax, 2) - 2);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(h->grid_row, (nint + 255) / 256));
+  };
+  const int g0 = grid_for(0), g1 = grid_for(1), g2 = grid_for(2);
+  hipLaunchKernelGGL((k_vcg_apply<T, 0>), dim3(g0), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[0],
+                     partial + used, done);
+  used += g0;
+  hipLaunchKernelGGL((k_vcg_apply<T, 1>), dim3(g1), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[1],
+                     partial + used, done);
+  used += g1;
+  hipLaunchKernelGGL((k_vcg_apply<T, 2>), dim3(g2), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[2],
+                     partial + used, done);
+  used += g2;
+  MFS_LAUNCH_CHECK();
+  *nparts = used;
+  return MFS_OK;
+}
+
+static int vcg_apply(mfs_vcg3d* h, const void* v, void* out, double* partial, bool use_done, hipStream_t st,
+                     int* nparts) {
+  if (h->g.N[0] < 2 || h->g.N[1] < 2 || h->g.N[2] < 2) { *nparts = 0; return MFS_OK; }
+  const double* done = use_done ? h->c.scal + S_DONE : nullptr;
+  return h->dt == MFS_F32 ? vcg_apply_T<float>(h, v, out, partial, done, st, nparts)
+                          : vcg_apply_T<double>(h, v, out, partial, done, st, nparts);
+}
+
+extern "C" {
+
+size_t mfs_visc_extrapolate3d_workspace_bytes(const int64_t gres[3], int v_dt) {
+  if (!gres || !dtype_ok(v_dt)) return 0;
+  G3 g = make_g(gres);
+  size_t tot = 0;
+  for (int c = 0; c < 3; ++c) tot += align_up((size_t)g.nface(c) * dtype_size(v_dt), 256) + 2 * align_up((size_t)g.nface(c), 256);
+  return tot;
+}
+
+int mfs_visc_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
+                           const void* sphi, int sphi_dt, void* workspace, size_t workspace_bytes,
+                           mfs_stream stream) {
+  if (int e = check_gres(gres)) return e;
+  MFS_REQUIRE(vx && vy && vz && sphi && workspace, "null array");
+  MFS_REQUIRE(dtype_ok(v_dt) && dtype_ok(sphi_dt), "dtype");
+  MFS_REQUIRE(num_iter >= 0, "num_iter");
+  MFS_REQUIRE(workspace_bytes >= mfs_visc_extrapolate3d_workspace_bytes(gres, v_dt), "workspace too small");
+  MFS_REQUIRE(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  G3 g = make_g(gres);
+  void* v[3] = {vx, vy, vz};
+  char* p = (char*)workspace;
+  for (int c = 0; c < 3; ++c) {
+    const int64_t n = g.nface(c);
+    void* tmp = p; p += align_up((size_t)n * dtype_size(v_dt), 256);
+    unsigned char* va = (unsigned char*)p; p += align_up((size_t)n, 256);
+    unsigned char* vb = (unsigned char*)p; p += align_up((size_t)n, 256);
+    const int grid = cdiv(n, 256);
+    if (c == 0) hipLaunchKernelGGL((k_visc_valid<0>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
+    if (c == 1) hipLaunchKernelGGL((k_visc_valid<1>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
+    if (c == 2) hipLaunchKernelGGL((k_visc_valid<2>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
+    void *cur = v[c], *oth = tmp;
+    unsigned char *mcur = va, *moth = vb;
+    for (int it = 0; it < num_iter; ++it) {
+      hipLaunchKernelGGL(k_visc_extrap_sweep, dim3(grid), dim3(256), 0, st, g.sh(c, 0), g.sh(c, 1), g.sh(c, 2), cur, oth,
+                         v_dt, mcur, moth);
+      std::swap(cur, oth);
+      std::swap(mcur, moth);
+    }
+    MFS_LAUNCH_CHECK();
+    if (cur != v[c]) MFS_HIP_TRY(hipMemcpyAsync(v[c], cur, (size_t)n * dtype_size(v_dt), hipMemcpyDeviceToDevice, st));
+  }
+  return MFS_OK;
+}
+
+int mfs_visc_rhs3d(const int64_t gres[3], double scale, double mu, const void* vx, const void* vy, const void* vz,
+                   int v_dt, const void* sphi, int sphi_dt, const void* vol, int vol_dt, void* b_x, void* b_y,
+                   void* b_z, int b_dt, mfs_stream stream) {
+  return launch_rows_direct<true>(gres, scale, mu, vx, vy, vz, v_dt, b_x, b_y, b_z, b_dt, sphi, sphi_dt, vol, vol_dt,
+                                  (hipStream_t)stream);
+}
+
+int mfs_visc_apply3d(const int64_t gres[3], double scale, double mu, const void* vx, const void* vy, const void* vz,
+                     int v_dt, void* out_x, void* out_y, void* out_z, int out_dt, const void* sphi, int sphi_dt,
+                     const void* vol, int vol_dt, mfs_stream stream) {
+  MFS_REQUIRE(vx != out_x && vy != out_y && vz != out_z, "apply cannot run in place");
+  return launch_rows_direct<false>(gres, scale, mu, vx, vy, vz, v_dt, out_x, out_y, out_z, out_dt, sphi, sphi_dt, vol,
+                                   vol_dt, (hipStream_t)stream);
+}
+
+int mfs_visc_writeback3d(const int64_t gres[3], void* vx, void* vy, void* vz, int v_dt, const void* out_x,
+                         const void* out_y, const void* out_z, int out_dt, const void* sphi, int sphi_dt,
+                         mfs_stream stream) {
+  if (int e = check_gres(gres)) return e;
+  MFS_REQUIRE(vx && vy && vz && out_x && out_y && out_z && sphi, "null array");
+  MFS_REQUIRE(dtype_ok(v_dt) && dtype_ok(out_dt) && dtype_ok(sphi_dt), "dtype");
+  G3 g = make_g(gres);
+  W3 v{{vx, vy, vz}};
+  V3 o{{out_x, out_y, out_z}};
+  const int64_t n = gres[0] * gres[1] * gres[2];
+  hipLaunchKernelGGL(k_visc_writeback, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, g, v, v_dt, o, out_dt,
+                     sphi, sphi_dt);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+// ------------------------------------------------------------------ engine ---
+size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
+  if (!gres || !dtype_ok(dt)) return 0;
+  size_t tot = core_ws_bytes() + 4096;
+  for (int p = 1; p < 8; ++p) tot += align_up((size_t)class_count(gres, p) * dtype_size(dt), 4096) + 4096;
+  for (int p : {3, 5, 6}) tot += align_up((size_t)class_count(gres, p), 4096);
+  return tot;
+}
+
+int64_t mfs_vcg3d_dofs(const int64_t gres[3]) {
+  if (!gres) return 0;
+  G3 g = make_g(gres);
+  return g.nface(0) + g.nface(1) + g.nface(2);
+}
+
+int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* workspace, size_t workspace_bytes,
+                     mfs_stream stream) {
+  MFS_REQUIRE(out && workspace, "null argument");
+  if (int e = check_gres(gres)) return e;
+  MFS_REQUIRE(dtype_ok(dt), "dtype");
+  MFS_REQUIRE(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+  MFS_REQUIRE(workspace_bytes >= mfs_vcg3d_workspace_bytes(gres, dt), "workspace too small");
+  mfs_vcg3d* h = new mfs_vcg3d();
+  h->g = make_g(gres);
+  h->dt = dt;
+  h->n = 0;
+  for (int c = 0; c < 3; ++c) { h->nf[c] = h->g.nface(c); h->off[c] = h->n; h->n += h->nf[c]; }
+  if (int e = core_init(h->c, dt, h->n)) { delete h; return e; }
+  h->ws = (char*)workspace; h->ws_bytes = workspace_bytes;
+  char* p = core_carve(h->c, h->ws);
+  p = (char*)align_up((uintptr_t)p, 4096);
+  for (int a = 0; a < 3; ++a) h->cp.N[a] = h->g.N[a];
+  h->cp.vol[0] = nullptr;
+  for (int q = 0; q < 8; ++q) h->cp.msk[q] = nullptr;
+  for (int q = 1; q < 8; ++q) { h->cp.vol[q] = p; p += align_up((size_t)class_count(gres, q) * h->c.elt, 4096) + 4096; }
+  for (int q : {3, 5, 6}) { h->cp.msk[q] = (unsigned char*)p; p += align_up((size_t)class_count(gres, q), 4096); }
+  h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
+  h->is_setup = false;
+  h->k1 = h->k2 = 0.0;
+  if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
+    set_error("hipMemsetAsync(workspace) failed");
+    core_free(h->c);
+    delete h;
+    return MFS_E_HIP;
+  }
+  *out = h;
+  return MFS_OK;
+}
+
+int mfs_vcg3d_destroy(mfs_vcg3d* h) {
+  if (!h) return MFS_OK;
+  core_free(h->c);
+  delete h;
+  return MFS_OK;
+}
+
+int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int sphi_dt, const void* vol, int vol_dt,
+                    mfs_stream stream) {
+  MFS_REQUIRE(h && sphi && vol, "null argument");
+  MFS_REQUIRE(dtype_ok(sphi_dt) && dtype_ok(vol_dt), "dtype");
+  const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
+  const int64_t n = (int64_t)(2 * Nx + 1) * (2 * Ny + 1) * (2 * Nz + 1);
+  unsigned char *m3 = (unsigned char*)h->cp.msk[3], *m5 = (unsigned char*)h->cp.msk[5], *m6 = (unsigned char*)h->cp.msk[6];
+  void* const* v = (void* const*)h->cp.vol;
+  if (h->dt == MFS_F32)
+    hipLaunchKernelGGL((k_vcg_setup<float>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, sphi,
+                       sphi_dt, vol, vol_dt, (float*)v[1], (float*)v[2], (float*)v[3], (float*)v[4], (float*)v[5],
+                       (float*)v[6], (float*)v[7], m3, m5, m6);
+  else
+    hipLaunchKernelGGL((k_vcg_setup<double>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, sphi,
+                       sphi_dt, vol, vol_dt, (double*)v[1], (double*)v[2], (double*)v[3], (double*)v[4],
+                       (double*)v[5], (double*)v[6], (double*)v[7], m3, m5, m6);
+  MFS_LAUNCH_CHECK();
+  h->k1 = scale * mu;          // `scale * mu * ...`      (left to right, as the reference evaluates it)
+  h->k2 = 2 * scale * mu;      // `2 * scale * mu * ...`
+  h->is_setup = true;
+  return MFS_OK;
+}
+
+int mfs_vcg3d_apply(mfs_vcg3d* h, const void* v, void* out, mfs_stream stream) {
+  MFS_REQUIRE(h && v && out && v != out, "null / aliased argument");
+  MFS_REQUIRE(h->is_setup, "mfs_vcg3d_setup has not been called");
+  int np = 0;
+  if (int e = vcg_apply(h, v, out, h->c.part_dq, false, (hipStream_t)stream, &np)) return e;
+  h->c.n_part_dq = np;
+  return MFS_OK;
+}
+
+int mfs_vcg3d_bind(mfs_vcg3d* h, void* b, void* x, void* d, void* r, void* q) {
+  MFS_REQUIRE(h, "null handle");
+  return core_bind(h->c, b, x, d, r, q);
+}
+
+int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = core_begin_pre(h->c, tol, false, st)) return e;     // x keeps the extrapolated velocity (:569-573)
+  int np = 0;
+  if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, st, &np)) return e;   // :575
+  if (int e = core_begin_post(h->c, st)) return e;                // :577-585
+  return core_begin_finish(h->c, st);
+}
+
+int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i = 0; i < n; ++i) {
+    int e, np = 0;
+    if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, st, &np))) return e;   // :589
+    h->c.n_part_dq = np;
+    if ((e = core_reduce(h->c, 0, 1, st))) return e;                                  // :592
+    if ((e = core_update_xr(h->c, st))) return e;                                     // :594-601
+    if ((e = core_reduce(h->c, 1, 1, st))) return e;                                  // :604
+    if ((e = core_update_d(h->c, st))) return e;                                      // :605-610
+  }
+  return MFS_OK;
+}
+
+int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters, int* done, double* delta, double* alpha,
+                   double* beta) {
+  MFS_REQUIRE(h, "null handle");
+  return core_poll(h->c, (hipStream_t)stream, iters, done, delta, alpha, beta);
+}
+
+int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every, mfs_stream stream,
+                    int64_t* iters_host) {
+  MFS_REQUIRE(h, "null handle");
+  MFS_REQUIRE(max_iter >= 0 && check_every >= 1, "max_iter / check_every");
+  if (int e = mfs_vcg3d_begin(h, tol, stream)) return e;
+  int64_t enq = 0, iters = 0;
+  int done = 0;
+  if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  while (!done && enq < max_iter) {
+    const int64_t n = std::min(check_every, max_iter - enq);
+    if (int e = mfs_vcg3d_iterate(h, n, stream)) return e;
+    enq += n;
+    if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  }
+  if (iters_host) *iters_host = iters;
+  return done ? MFS_OK : MFS_NOT_CONVERGED;
+}
+
+int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream) {
+  if (!h) { set_error("mfs_vcg3d_history: null handle"); return MFS_E_INVALID; }
+  return core_history(h->c, out_host, cap, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -65,6 +65,23 @@ SIGNATURES = {
     "mfs_pcg3d_begin_finish": (_i, [_p, _p]),
     "mfs_pcg3d_scalars": (_p, [_p]),
     "mfs_pcg3d_tune": (_i, [_p, _i, _i, _i, _i]),
+    "mfs_visc_extrapolate3d_workspace_bytes": (_sz, [_pi64, _i]),
+    "mfs_visc_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _i, _p, _sz, _p]),
+    "mfs_visc_rhs3d": (_i, [_pi64, _d, _d, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),
+    "mfs_visc_apply3d": (_i, [_pi64, _d, _d, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
+    "mfs_visc_writeback3d": (_i, [_pi64, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i, _p]),
+    "mfs_vcg3d_workspace_bytes": (_sz, [_pi64, _i]),
+    "mfs_vcg3d_dofs": (_i64, [_pi64]),
+    "mfs_vcg3d_create": (_i, [C.POINTER(_p), _pi64, _i, _p, _sz, _p]),
+    "mfs_vcg3d_destroy": (_i, [_p]),
+    "mfs_vcg3d_setup": (_i, [_p, _d, _d, _p, _i, _p, _i, _p]),
+    "mfs_vcg3d_apply": (_i, [_p, _p, _p, _p]),
+    "mfs_vcg3d_bind": (_i, [_p, _p, _p, _p, _p, _p]),
+    "mfs_vcg3d_begin": (_i, [_p, _d, _p]),
+    "mfs_vcg3d_iterate": (_i, [_p, _i64, _p]),
+    "mfs_vcg3d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
+    "mfs_vcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
+    "mfs_vcg3d_history": (_i64, [_p, _pd, _i64, _p]),
 }
 
 _lib = None

@@ -1,0 +1,99 @@
+"""Python owner of one `mfs_vcg3d` engine handle (include/mfs.h): the viscosity CG."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, tensors as T
+
+
+class VcgEngine:
+    def __init__(self, gres, dtype, device=None):
+        self.lib = _lib.load()
+        self.gres = T.as_gres(gres)
+        if len(self.gres) != 3:
+            raise ValueError("VcgEngine is 3D")
+        self.dtype = T.state_dtype(dtype)
+        self.code = _lib.MFS_F32 if self.dtype == torch.float32 else _lib.MFS_F64
+        self.device = torch.device("cuda" if device is None else device)
+        g = _lib.i64x(self.gres)
+        self.dofs = int(self.lib.mfs_vcg3d_dofs(g))
+        self.face_shapes = [T.face_shape(self.gres, a) for a in range(3)]
+        nbytes = int(self.lib.mfs_vcg3d_workspace_bytes(g, self.code))
+        if nbytes <= 0:
+            raise _lib.MfsError("mfs_vcg3d_workspace_bytes returned 0")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mfs_vcg3d_create(C.byref(h), g, self.code, T.ptr(self.workspace), nbytes, T.stream()),
+                       "mfs_vcg3d_create")
+        self.h = h
+        self._bound = None
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.mfs_vcg3d_destroy(h)
+            except Exception:
+                pass
+
+    def new_vector(self):
+        """flat [x-faces | y-faces | z-faces] vector plus its three component views"""
+        flat = torch.zeros(self.dofs, dtype=self.dtype, device=self.device)
+        views, o = [], 0
+        for shp in self.face_shapes:
+            n = int(np.prod(shp))
+            views.append(flat[o:o + n].view(shp))
+            o += n
+        return flat, views
+
+    def setup(self, scale, mu, sphi, vol):
+        sphi = T.dev(sphi, "sphi", T.doubled_shape(self.gres))
+        vol = T.dev(vol, "vol", T.doubled_shape(self.gres))
+        _lib.check(self.lib.mfs_vcg3d_setup(self.h, float(scale), float(mu), T.ptr(sphi), T.code(sphi), T.ptr(vol),
+                                            T.code(vol), T.stream()), "mfs_vcg3d_setup")
+
+    def _flat(self, t, name):
+        t = T.dev(t, name, (self.dofs,))
+        if t.dtype != self.dtype:
+            raise TypeError(f"{name} must be {self.dtype}")
+        return t
+
+    def apply(self, v, out):
+        v, out = self._flat(v, "v"), self._flat(out, "out")
+        _lib.check(self.lib.mfs_vcg3d_apply(self.h, T.ptr(v), T.ptr(out), T.stream()), "mfs_vcg3d_apply")
+
+    def bind(self, b, x, d, r, q):
+        ts = [self._flat(a, n) for a, n in ((b, "b"), (x, "x"), (d, "d"), (r, "r"), (q, "q"))]
+        _lib.check(self.lib.mfs_vcg3d_bind(self.h, *[T.ptr(t) for t in ts]), "mfs_vcg3d_bind")
+        self._bound = ts
+
+    def begin(self, tol):
+        _lib.check(self.lib.mfs_vcg3d_begin(self.h, float(tol), T.stream()), "mfs_vcg3d_begin")
+
+    def iterate(self, n):
+        _lib.check(self.lib.mfs_vcg3d_iterate(self.h, int(n), T.stream()), "mfs_vcg3d_iterate")
+
+    def poll(self):
+        it, done = C.c_int64(), C.c_int()
+        delta, alpha, beta = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib.mfs_vcg3d_poll(self.h, T.stream(), C.byref(it), C.byref(done), C.byref(delta),
+                                           C.byref(alpha), C.byref(beta)), "mfs_vcg3d_poll")
+        return dict(iterations=it.value, done=bool(done.value), delta=delta.value, alpha=alpha.value,
+                    beta=beta.value)
+
+    def solve(self, tol, max_iter, check_every=32):
+        it = C.c_int64()
+        st = _lib.check(self.lib.mfs_vcg3d_solve(self.h, float(tol), int(max_iter), int(check_every), T.stream(),
+                                                 C.byref(it)), "mfs_vcg3d_solve")
+        return st == _lib.MFS_OK, it.value
+
+    def history(self):
+        cap = int(self.lib.mfs_pcg3d_history_capacity())
+        buf = np.empty(cap, dtype=np.float64)
+        n = self.lib.mfs_vcg3d_history(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), cap, T.stream())
+        _lib.check(int(n), "mfs_vcg3d_history")
+        return buf[: int(n)].copy()

@@ -1,0 +1,135 @@
+"""Drop-in for the reference's solver/ViscosityCGSolver3D.py on MI355X.
+
+Same module functions (`extrapolate`, `initialize_solver`, `matvecmul`,
+`apply_viscosity`), class, constructor and `solve` signature as the reference,
+on PyTorch-ROCm tensors, calling the HIP kernels of libmfs_hip.so through the C
+ABI (include/mfs.h).  No CPU path.
+"""
+import numpy as np
+import torch
+
+from mfs import _lib, tensors as T
+from mfs.vcg import VcgEngine
+
+
+def _comps(g, a, b, c, names):
+    out = [T.dev(t, n, T.face_shape(g, ax)) for ax, (t, n) in enumerate(zip((a, b, c), names))]
+    if not (out[0].dtype == out[1].dtype == out[2].dtype):
+        raise TypeError(f"{names} must share a dtype")
+    return out
+
+
+def extrapolate(gres, num_iter, vx, vy, vz, sphi):
+    """`num_iter` Jacobi sweeps of the 6-neighbour average into solid faces, in place
+    (reference :472-502 -> kernel :8-39)."""
+    g = T.as_gres(gres)
+    vx, vy, vz = _comps(g, vx, vy, vz, ("vx", "vy", "vz"))
+    sphi = T.dev(sphi, "sphi", T.doubled_shape(g))
+    lib = _lib.load()
+    gi = _lib.i64x(g)
+    nbytes = int(lib.mfs_visc_extrapolate3d_workspace_bytes(gi, T.code(vx)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=vx.device)
+    _lib.check(lib.mfs_visc_extrapolate3d(gi, int(num_iter), T.ptr(vx), T.ptr(vy), T.ptr(vz), T.code(vx), T.ptr(sphi),
+                                          T.code(sphi), T.ptr(ws), nbytes, T.stream()), "mfs_visc_extrapolate3d")
+
+
+def initialize_solver(gres, scale, mu, vx, vy, vz, sphi, sv, vol, b_x, b_y, b_z):
+    """viscosity RHS (reference :504-513 -> kernels :41-246).  `sv` is accepted and unused,
+    exactly as in the reference (Q12)."""
+    g = T.as_gres(gres)
+    vx, vy, vz = _comps(g, vx, vy, vz, ("vx", "vy", "vz"))
+    b_x, b_y, b_z = _comps(g, b_x, b_y, b_z, ("b_x", "b_y", "b_z"))
+    sphi = T.dev(sphi, "sphi", T.doubled_shape(g))
+    vol = T.dev(vol, "vol", T.doubled_shape(g))
+    lib = _lib.load()
+    _lib.check(lib.mfs_visc_rhs3d(_lib.i64x(g), float(scale), float(mu), T.ptr(vx), T.ptr(vy), T.ptr(vz), T.code(vx),
+                                  T.ptr(sphi), T.code(sphi), T.ptr(vol), T.code(vol), T.ptr(b_x), T.ptr(b_y),
+                                  T.ptr(b_z), T.code(b_x), T.stream()), "mfs_visc_rhs3d")
+
+
+def matvecmul(gres, scale, mu, vx, vy, vz, out_x, out_y, out_z, sphi, vol):
+    """the coupled 3-component viscosity operator (reference :515-524 -> kernels :248-456)."""
+    g = T.as_gres(gres)
+    vx, vy, vz = _comps(g, vx, vy, vz, ("vx", "vy", "vz"))
+    out_x, out_y, out_z = _comps(g, out_x, out_y, out_z, ("out_x", "out_y", "out_z"))
+    sphi = T.dev(sphi, "sphi", T.doubled_shape(g))
+    vol = T.dev(vol, "vol", T.doubled_shape(g))
+    lib = _lib.load()
+    _lib.check(lib.mfs_visc_apply3d(_lib.i64x(g), float(scale), float(mu), T.ptr(vx), T.ptr(vy), T.ptr(vz),
+                                    T.code(vx), T.ptr(out_x), T.ptr(out_y), T.ptr(out_z), T.code(out_x), T.ptr(sphi),
+                                    T.code(sphi), T.ptr(vol), T.code(vol), T.stream()), "mfs_visc_apply3d")
+
+
+def apply_viscosity(gres, vx, vy, vz, out_x, out_y, out_z, sphi, sv):
+    """copy the solution into the non-solid faces of vx,vy,vz, in place (reference :526-530 -> :458-470)."""
+    g = T.as_gres(gres)
+    vx, vy, vz = _comps(g, vx, vy, vz, ("vx", "vy", "vz"))
+    out_x, out_y, out_z = _comps(g, out_x, out_y, out_z, ("out_x", "out_y", "out_z"))
+    sphi = T.dev(sphi, "sphi", T.doubled_shape(g))
+    lib = _lib.load()
+    _lib.check(lib.mfs_visc_writeback3d(_lib.i64x(g), T.ptr(vx), T.ptr(vy), T.ptr(vz), T.code(vx), T.ptr(out_x),
+                                        T.ptr(out_y), T.ptr(out_z), T.code(out_x), T.ptr(sphi), T.code(sphi),
+                                        T.stream()), "mfs_visc_writeback3d")
+
+
+class ViscosityCGSolver3D:
+    """Reference :532-613.  `ViscosityCGSolver3D(gres, bound_size)`;
+    `solve(dt, mu, rho, vx, vy, vz, sphi, sv, lphi, lvol, tol=1e-3)`.
+
+    The 15 solver-owned CG arrays keep the reference's names and shapes (`x_x`,
+    `d_y`, ...); each is a view into one flat per-vector allocation so the vector
+    phases of the CG run as single launches over all three components.
+    Extras: `iterations`, `history`; `precision` / MFS_PRECISION selects fp32 state.
+    """
+
+    def __init__(self, gres, bound_size, precision=None, device=None, check_every=32):
+        self.gres = gres
+        self._g = T.as_gres(gres)
+        if len(self._g) != 3:
+            raise ValueError("ViscosityCGSolver3D needs a 3D grid")
+        self.cell_size = np.array(T.as_f64_list(bound_size, 3)) / np.array(self._g, dtype=np.float64)
+        self.cell_vol = float(np.prod(self.cell_size))
+        dt = T.state_dtype(precision)
+        device = torch.device("cuda" if device is None else device)
+        self._engine = VcgEngine(self._g, dt, device)
+        self.vol = torch.zeros(T.doubled_shape(self._g), dtype=torch.float64, device=device)
+        self._flat = {}
+        for nm in "drqxb":
+            flat, views = self._engine.new_vector()
+            self._flat[nm] = flat
+            for c, v in zip("xyz", views):
+                setattr(self, f"{nm}_{c}", v)
+        self.alpha = 0.0
+        self.beta = 0.0
+        self.delta = 0.0
+        self.max_iter = int(np.prod(self._g))
+        self.check_every = int(check_every)
+        self.iterations = 0
+
+    @property
+    def history(self):
+        return self._engine.history()
+
+    def solve(self, dt, mu, rho, vx, vy, vz, sphi, sv, lphi, lvol, tol=1e-3):
+        g = self._g
+        scale = dt / self.cell_vol / rho                                   # :567
+        lvol = T.dev(lvol, "lvol", T.doubled_shape(g))
+        vx, vy, vz = _comps(g, vx, vy, vz, ("vx", "vy", "vz"))
+        eng = self._engine
+        with torch.cuda.device(self.vol.device):
+            torch.div(lvol, self.cell_vol * 0.125, out=self.vol)           # :568
+            self.x_x.copy_(vx)                                             # :569-571 (dtype cast)
+            self.x_y.copy_(vy)
+            self.x_z.copy_(vz)
+            extrapolate(g, 3, self.x_x, self.x_y, self.x_z, sphi)          # :573
+            initialize_solver(g, scale, mu, self.x_x, self.x_y, self.x_z, sphi, sv, self.vol,
+                              self.b_x, self.b_y, self.b_z)                # :574
+            eng.setup(scale, mu, sphi, self.vol)
+            f = self._flat
+            eng.bind(f["b"], f["x"], f["d"], f["r"], f["q"])
+            ok, self.iterations = eng.solve(tol, self.max_iter, self.check_every)   # :575-612
+            st = eng.poll()
+            self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
+            if not ok:
+                raise ValueError("Failed to converge!")
+            apply_viscosity(g, vx, vy, vz, self.x_x, self.x_y, self.x_z, sphi, sv)   # :613
