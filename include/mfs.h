@@ -203,6 +203,37 @@ int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_ev
                     mfs_stream stream, int64_t* iters_host);
 int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream);
 
+/* ------------------------------------------------------------------------- */
+/* Pressure, 2D (BASELINE config 1) -- reference solver/PressureCGSolver2D.py    */
+/* ------------------------------------------------------------------------- */
+/* replaces initialize_solver -- solver/PressureCGSolver2D.py:6-44,122-126 */
+int mfs_pressure_rhs2d(const int64_t gres[2], const double cell_size[2],
+                       const void* vx, const void* vy, int v_dt, const void* sv, int sv_dt,
+                       const void* lphi, int lphi_dt, const void* wx, const void* wy, int w_dt,
+                       void* b, int b_dt, mfs_stream stream);
+/* replaces matvecmul -- solver/PressureCGSolver2D.py:46-100,128-132 */
+int mfs_pressure_apply2d(const int64_t gres[2], const void* v, void* out, int dt,
+                         const void* wx, const void* wy, int w_dt, const void* lphi, int lphi_dt,
+                         mfs_stream stream);
+/* replaces apply_pressure -- solver/PressureCGSolver2D.py:102-120,134-138 */
+int mfs_pressure_update2d(const int64_t gres[2], const double cell_size[2], void* vx, void* vy, int v_dt,
+                          const void* pv, int pv_dt, const void* wx, const void* wy, int w_dt,
+                          const void* sv, int sv_dt, const void* lphi, int lphi_dt, mfs_stream stream);
+/* the CG loop solver/PressureCGSolver2D.py:159-177 (no error on non-convergence in the reference:
+ * mfs_pcg2d_solve returns MFS_NOT_CONVERGED and the caller carries on)                             */
+typedef struct mfs_pcg2d mfs_pcg2d;
+size_t mfs_pcg2d_workspace_bytes(const int64_t gres[2], int dt);
+int mfs_pcg2d_create(mfs_pcg2d** out_host, const int64_t gres[2], int dt,
+                     void* workspace, size_t workspace_bytes, mfs_stream stream);
+int mfs_pcg2d_destroy(mfs_pcg2d* h);
+int mfs_pcg2d_setup(mfs_pcg2d* h, const void* lphi, int lphi_dt, const void* wx, const void* wy, int w_dt);
+int mfs_pcg2d_bind(mfs_pcg2d* h, void* b, void* x, void* d, void* r, void* q);
+int mfs_pcg2d_solve(mfs_pcg2d* h, double tol, int64_t max_iter, int64_t check_every,
+                    mfs_stream stream, int64_t* iters_host);
+int mfs_pcg2d_poll(mfs_pcg2d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
+                   double* delta_host, double* alpha_host, double* beta_host);
+int64_t mfs_pcg2d_history(mfs_pcg2d* h, double* out_host, int64_t cap, mfs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

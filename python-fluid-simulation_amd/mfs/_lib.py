@@ -82,6 +82,17 @@ SIGNATURES = {
     "mfs_vcg3d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
     "mfs_vcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
     "mfs_vcg3d_history": (_i64, [_p, _pd, _i64, _p]),
+    "mfs_pressure_rhs2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
+    "mfs_pressure_apply2d": (_i, [_pi64, _p, _p, _i, _p, _p, _i, _p, _i, _p]),
+    "mfs_pressure_update2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p]),
+    "mfs_pcg2d_workspace_bytes": (_sz, [_pi64, _i]),
+    "mfs_pcg2d_create": (_i, [C.POINTER(_p), _pi64, _i, _p, _sz, _p]),
+    "mfs_pcg2d_destroy": (_i, [_p]),
+    "mfs_pcg2d_setup": (_i, [_p, _p, _i, _p, _p, _i]),
+    "mfs_pcg2d_bind": (_i, [_p, _p, _p, _p, _p, _p]),
+    "mfs_pcg2d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
+    "mfs_pcg2d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
+    "mfs_pcg2d_history": (_i64, [_p, _pd, _i64, _p]),
 }
 
 _lib = None
