@@ -7,10 +7,16 @@
 // only `apply` differs.  One iteration:
 //
 //   <apply>          q = A d, per-block partials of d.q
-//   k_reduce(DQ)     1 block: partials -> scalars[DQ]        (+ DELTA <- RR)
-//   k_update_xr      x += a d ; r -= a q ; partials of r.r            6 scalars/DOF
-//   k_reduce(RR)     1 block: partials -> scalars[RR]
-//   k_update_d       convergence test, history, d = r + b d           3 scalars/DOF
+//   k_update_xr      a = delta / d.q ; x += a d ; r -= a q ; partials of r.r   6 scalars/DOF
+//   k_update_d       convergence test, history, b, d = r + b d                 3 scalars/DOF
+//
+// The two dot products have no kernel of their own on one GPU: every block of the
+// consuming kernel sums the producer's per-block partials itself (<= 8192 doubles
+// out of L2, same fixed order in every block => identical value everywhere).  The
+// multi-GPU driver needs the sums as scalars to all-reduce, so there the 1-block
+// k_reduce runs between producer and consumer and the consumers read the scalars.
+// delta is kept in a 2-slot ring indexed by iteration parity (a kernel argument), so
+// no kernel reads a scalar that the same kernel's bookkeeping thread rewrites.
 //
 // alpha, beta, delta, the iteration count and a `done` flag live in device
 // memory; once `done` is set every later kernel is a no-op, so the iteration
@@ -33,7 +39,7 @@ constexpr int64_t kHistCap = 16384;
 
 enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TOL2 = MFS_PCG_S_TOL2,
        S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
-       S_LASTRR = MFS_PCG_S_LASTRR };
+       S_LASTRR = MFS_PCG_S_LASTRR, S_RING = 9 /* 2 slots: delta by iteration parity */ };
 
 
 template <typename T, int VEC>
@@ -41,11 +47,15 @@ __device__ __forceinline__ Vec<T, VEC> ldv(const T* p) { return *reinterpret_cas
 
 // ---------------------------------------------------------- vector phases ---
 template <typename T, int VEC, typename F>
-__device__ __forceinline__ void for_each_vec(int64_t n, F&& f) {
-  // f(i, lanes): process elements [i, i+lanes)
+__device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = false) {
+  // f(i, vec): process elements [i, i+VEC) (vec) or the single element i (tail).
+  // reverse: sweep from the end of the array to its start -- consecutive CG phases
+  // alternate direction so each one starts on the bytes the previous one touched
+  // last (still resident in the Infinity Cache) instead of the ones it evicted first.
   const int64_t nv = n / VEC;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride) f(k * VEC, true);
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride)
+    f((reverse ? nv - 1 - k : k) * VEC, true);
   // scalar tail (n % VEC elements) handled by the first threads of block 0
   const int64_t tail = n - nv * VEC;
   if (blockIdx.x == 0 && (int64_t)threadIdx.x < tail) f(nv * VEC + threadIdx.x, false);
@@ -78,33 +88,51 @@ k_cg_init(const T* __restrict__ b, const T* __restrict__ q, T* __restrict__ d, T
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// sum of partial[0..count) known to EVERY thread of the block (fixed order: deterministic)
+__device__ __forceinline__ double block_total_of(const double* __restrict__ partial, int count) {
+  __shared__ double s_tot;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) acc += partial[i];
+  const double t = block_sum<kBlock>(acc);
+  if (threadIdx.x == 0) s_tot = t;
+  __syncthreads();
+  return s_tot;
+}
+
 // alpha = delta / dq ; x += alpha d ; r -= alpha q ; partial sum r^2   (:211-216)
-template <typename T, int VEC>
+// NTX: x is touched once per iteration and by no other kernel -> stream it past the
+// caches (nontemporal load + store) so that d, r, q keep their Infinity-Cache lines.
+template <typename T, int VEC, bool NTX>
 __global__ void __launch_bounds__(kBlock)
 k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
-            const double* __restrict__ scal, double* __restrict__ partial) {
+            double* __restrict__ scal, double* __restrict__ partial, int rev, int par,
+            const double* __restrict__ part_dq, int npart) {
   if (scal[S_DONE] != 0.0) return;
-  const double alpha = scal[S_DELTA] / scal[S_DQ];
+  // d.q: folded reduction of the apply's partials (npart > 0) or the all-reduced scalar
+  const double dq = npart > 0 ? block_total_of(part_dq, npart) : scal[S_DQ];
+  if (npart > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;   // kept for the history entry
+  const double alpha = scal[S_RING + par] / dq;
   double acc = 0.0;
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
     if (vec) {
-      Vec<T, VEC> xv = ldv<T, VEC>(x + i), rv = ldv<T, VEC>(r + i);
-      const Vec<T, VEC> dv = ldv<T, VEC>(d + i), qv = ldv<T, VEC>(q + i);
+      vec_t<T, VEC> xv = NTX ? vload_nt<T, VEC>(x + i) : vload<T, VEC>(x + i);
+      vec_t<T, VEC> rv = vload<T, VEC>(r + i);
+      const vec_t<T, VEC> dv = vload<T, VEC>(d + i), qv = vload<T, VEC>(q + i);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        xv.v[j] = (T)((double)xv.v[j] + alpha * (double)dv.v[j]);
-        rv.v[j] = (T)((double)rv.v[j] - alpha * (double)qv.v[j]);
-        acc += (double)rv.v[j] * (double)rv.v[j];
+        xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
+        rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
+        acc += (double)rv[j] * (double)rv[j];
       }
-      *reinterpret_cast<Vec<T, VEC>*>(x + i) = xv;
-      *reinterpret_cast<Vec<T, VEC>*>(r + i) = rv;
+      if (NTX) vstore_nt<T, VEC>(x + i, xv); else vstore<T, VEC>(x + i, xv);
+      vstore<T, VEC>(r + i, rv);
     } else {
       const T xn = (T)((double)x[i] + alpha * (double)d[i]);
       const T rn = (T)((double)r[i] - alpha * (double)q[i]);
       x[i] = xn; r[i] = rn;
       acc += (double)rn * (double)rn;
     }
-  });
+  }, rev != 0);
   const double tot = block_sum<kBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
@@ -113,16 +141,21 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __restrict__ scal,
-           double* __restrict__ hist, int64_t hist_cap) {
+           double* __restrict__ hist, int64_t hist_cap, int rev, int par, const double* __restrict__ part_rr,
+           int npart) {
   if (scal[S_DONE] != 0.0) return;
-  const double rr = scal[S_RR], delta = scal[S_DELTA], tol2 = scal[S_TOL2];
+  const double rr = npart > 0 ? block_total_of(part_rr, npart) : scal[S_RR];
+  const double delta = scal[S_RING + par], tol2 = scal[S_TOL2];
   const bool conv = rr < tol2;
   const double beta = rr / delta;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const double dq = scal[S_DQ];
-    const int64_t it = (int64_t)scal[S_ITERS];
+    const int64_t it = (int64_t)scal[S_ITERS];     // only this thread ever writes ITERS
     if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
     scal[S_ITERS] = (double)(it + 1);
+    scal[S_RING + (par ^ 1)] = rr;                 // delta of the next iteration (other ring slot)
+    scal[S_RR] = rr;
+    scal[S_DELTA] = delta;
     scal[S_LASTRR] = rr;
     scal[S_ALPHA] = delta / dq;
     if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
@@ -138,7 +171,7 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
     } else {
       d[i] = (T)((double)r[i] + beta * (double)d[i]);
     }
-  });
+  }, rev != 0);
 }
 
 // x *= 0.0 (:198) -- a multiply, not a memset, so NaN/inf survive as in the reference.
@@ -157,7 +190,6 @@ k_reduce(const double* __restrict__ partial, int count, double* __restrict__ sca
   const double tot = block_sum<kBlock>(acc);
   if (threadIdx.x == 0) {
     scal[which] = tot;
-    if (which == S_DQ) scal[S_DELTA] = scal[S_RR];  // the iteration that starts here begins from the latest r.r
   }
 }
 
@@ -172,6 +204,7 @@ static __global__ void k_begin_finish(double* scal, double* hist) {
   if (threadIdx.x == 0) {
     const double rr = scal[S_RR];
     scal[S_DELTA] = rr;
+    scal[S_RING + 0] = rr;                       // iteration 0 starts from delta0 (parity 0)
     scal[S_LASTRR] = rr;
     hist[0] = rr;
     if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0;  // `if not self.delta < tol ** 2` (:206)
@@ -196,6 +229,9 @@ struct CgCore {
   void *b = nullptr, *x = nullptr, *d = nullptr, *r = nullptr, *q = nullptr;
   int n_part_dq = 0, n_part_rr = 0;
   int grid_vec = 2048, cus = 256;
+  int64_t iter_enq = 0;        // iterations enqueued since begin (its parity selects the delta ring slot)
+  int rev_xr = 0, rev_d = 0;   // sweep direction of the two vector phases (see for_each_vec)
+  int nt_x = -1;   // nontemporal x stream in k_update_xr: 1 on, 0 off, -1 auto (working set > Infinity Cache)
   double* pinned = nullptr;
 };
 
@@ -221,6 +257,9 @@ static inline int core_init(CgCore& c, int dt, int64_t n) {
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c.cus = prop.multiProcessorCount;
   }
   c.grid_vec = std::min(kMaxPartials, c.cus * env_int("MFS_VEC_BLOCKS_PER_CU", 8));
+  c.nt_x = env_int("MFS_NT_X", -1);
+  c.rev_xr = env_int("MFS_REV_XR", 0);
+  c.rev_d = env_int("MFS_REV_D", 0);
   if (hipHostMalloc((void**)&c.pinned, MFS_PCG_NSCALARS * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     set_error("hipHostMalloc for the poll buffer failed");
     return MFS_E_HIP;
@@ -261,34 +300,38 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
   return MFS_OK;
 }
 
-static inline int core_update_xr(CgCore& c, hipStream_t st) {
+#define MFS_XR(TT, VV, NN) \
+  hipLaunchKernelGGL((k_update_xr<TT, VV, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x, (const TT*)c.d, (TT*)c.r, \
+                     (const TT*)c.q, c.n, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), c.part_dq, fold ? c.n_part_dq : 0)
+static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st) {
   MFS_REQUIRE(c.x, "engine not bound");
   const bool vec = core_vec_ok(c);
   const int grid = core_vec_grid(c, vec);
+  const bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
   if (c.dt == MFS_F32) {
-    if (vec) hipLaunchKernelGGL((k_update_xr<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)c.x, (const float*)c.d, (float*)c.r, (const float*)c.q, c.n, c.scal, c.part_rr);
-    else hipLaunchKernelGGL((k_update_xr<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)c.x, (const float*)c.d, (float*)c.r, (const float*)c.q, c.n, c.scal, c.part_rr);
+    if (!vec) MFS_XR(float, 1, false); else if (ntx) MFS_XR(float, 4, true); else MFS_XR(float, 4, false);
   } else {
-    if (vec) hipLaunchKernelGGL((k_update_xr<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)c.x, (const double*)c.d, (double*)c.r, (const double*)c.q, c.n, c.scal, c.part_rr);
-    else hipLaunchKernelGGL((k_update_xr<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)c.x, (const double*)c.d, (double*)c.r, (const double*)c.q, c.n, c.scal, c.part_rr);
+    if (!vec) MFS_XR(double, 1, false); else if (ntx) MFS_XR(double, 2, true); else MFS_XR(double, 2, false);
   }
   MFS_LAUNCH_CHECK();
   c.n_part_rr = grid;
   return MFS_OK;
 }
+#undef MFS_XR
 
-static inline int core_update_d(CgCore& c, hipStream_t st) {
+static inline int core_update_d(CgCore& c, bool fold, hipStream_t st) {
   MFS_REQUIRE(c.d, "engine not bound");
   const bool vec = core_vec_ok(c);
   const int grid = core_vec_grid(c, vec);
   if (c.dt == MFS_F32) {
-    if (vec) hipLaunchKernelGGL((k_update_d<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap);
-    else hipLaunchKernelGGL((k_update_d<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap);
+    if (vec) hipLaunchKernelGGL((k_update_d<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0);
+    else hipLaunchKernelGGL((k_update_d<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0);
   } else {
-    if (vec) hipLaunchKernelGGL((k_update_d<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)c.d, (const double*)c.r, c.n, c.scal, c.hist, kHistCap);
-    else hipLaunchKernelGGL((k_update_d<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)c.d, (const double*)c.r, c.n, c.scal, c.hist, kHistCap);
+    if (vec) hipLaunchKernelGGL((k_update_d<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)c.d, (const double*)c.r, c.n, c.scal, c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0);
+    else hipLaunchKernelGGL((k_update_d<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)c.d, (const double*)c.r, c.n, c.scal, c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0);
   }
   MFS_LAUNCH_CHECK();
+  ++c.iter_enq;      // the d update closes an iteration
   return MFS_OK;
 }
 
@@ -297,6 +340,7 @@ static inline int core_begin_pre(CgCore& c, double tol, bool zero_x, hipStream_t
   MFS_REQUIRE(c.x, "engine not bound");
   hipLaunchKernelGGL(k_begin_init, dim3(1), dim3(64), 0, st, c.scal, tol * tol);
   MFS_LAUNCH_CHECK();
+  c.iter_enq = 0;
   if (zero_x) {
     const int gs = std::max(1, (int)std::min<int64_t>(c.grid_vec, (c.n + kBlock - 1) / kBlock));
     if (c.dt == MFS_F32) hipLaunchKernelGGL((k_scale0<float>), dim3(gs), dim3(kBlock), 0, st, (float*)c.x, c.n);

@@ -76,6 +76,24 @@ struct alignas(sizeof(T) * VEC) Vec {
   T v[VEC];
 };
 
+// native 16-byte vectors (float4 / double2) so the nontemporal builtins apply
+template <typename T, int N> struct NativeVec { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T> struct NativeVec<T, 1> { typedef T type __attribute__((ext_vector_type(1))); };
+template <typename T, int N> using vec_t = typename NativeVec<T, N>::type;
+
+template <typename T, int VEC>
+__device__ __forceinline__ vec_t<T, VEC> vload(const T* p) { return *reinterpret_cast<const vec_t<T, VEC>*>(p); }
+template <typename T, int VEC>
+__device__ __forceinline__ vec_t<T, VEC> vload_nt(const T* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const vec_t<T, VEC>*>(p));
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void vstore(T* p, vec_t<T, VEC> v) { *reinterpret_cast<vec_t<T, VEC>*>(p) = v; }
+template <typename T, int VEC>
+__device__ __forceinline__ void vstore_nt(T* p, vec_t<T, VEC> v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<vec_t<T, VEC>*>(p));
+}
+
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int N = 4; };
 template <> struct VecOf<double> { static constexpr int N = 2; };

@@ -69,7 +69,7 @@ struct mfs_pcg3d {
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
   int grid_apply, cus;
-  int variant, xchunk, nt, bpc;   // apply-kernel tuning (mfs_pcg3d_tune)
+  int variant, xchunk, nt, bpc, nt_auto;   // apply-kernel tuning (mfs_pcg3d_tune)
   bool vec_ok;
   bool is_setup;
 };
@@ -102,14 +102,24 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, doub
     // Nontemporal loads for the once-read coefficient streams pay off only when the
     // apply's working set (6 arrays) cannot sit in the 256 MiB Infinity Cache anyway;
     // below that, default caching lets the next iteration hit on-die.  nt < 0 = auto.
-    const bool nt = h->nt < 0 ? (6.0 * (double)h->n * sizeof(T) > 200e6) : (h->nt != 0);
+    // bit 0: diag, cz   bit 1: cx   bit 2: cy   -- the once-per-iteration coefficient streams.
+    // < 0 = auto: all of them when the apply's six arrays exceed the Infinity Cache.
+    const int nt = h->nt < 0 ? ((6.0 * (double)h->n * sizeof(T) > 200e6) ? h->nt_auto : 0) : (h->nt & 7);
+#define MFS_MARCH(LDSF, NTV) \
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, v, out, \
+                       dg, cx, cy, cz, a, partial, done)
     if (variant == 2) {
-      if (nt) hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, 1>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, a, partial, done);
-      else    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, 0>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, a, partial, done);
+      switch (nt) {
+        case 0: MFS_MARCH(true, 0); break;
+        case 1: MFS_MARCH(true, 1); break;
+        case 3: MFS_MARCH(true, 3); break;
+        case 5: MFS_MARCH(true, 5); break;
+        default: MFS_MARCH(true, 7); break;
+      }
     } else {
-      if (nt) hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, false, 1>), dim3(grid), dim3(kApplyBlock), 0, st, v, out, dg, cx, cy, cz, a, partial, done);
-      else    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, false, 0>), dim3(grid), dim3(kApplyBlock), 0, st, v, out, dg, cx, cy, cz, a, partial, done);
+      if (nt) MFS_MARCH(false, 1); else MFS_MARCH(false, 0);
     }
+#undef MFS_MARCH
     *grid_out = grid;
   }
   MFS_LAUNCH_CHECK();
@@ -167,6 +177,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->variant = env_int("MFS_APPLY_VARIANT", 2);
   h->xchunk = env_int("MFS_APPLY_XCHUNK", 0);
   h->nt = env_int("MFS_APPLY_NT", -1);
+  h->nt_auto = env_int("MFS_APPLY_NT_AUTO", 7);
   h->bpc = env_int("MFS_APPLY_BLOCKS_PER_CU", 2);
   h->grid_apply = std::min(kMaxPartials, h->cus * 8);
   h->is_setup = false;
@@ -225,7 +236,13 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
   MFS_REQUIRE(h, "null handle");
   MFS_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0 (direct), 1 (march) or 2 (march + LDS)");
   MFS_REQUIRE(xchunk >= 0 && blocks_per_cu >= 1, "xchunk must be >= 0 (0 = no cap), blocks_per_cu >= 1");
-  h->variant = variant; h->xchunk = xchunk; h->nt = nontemporal; h->bpc = blocks_per_cu;
+  h->variant = variant; h->xchunk = xchunk; h->bpc = blocks_per_cu;
+  h->nt = nontemporal < 0 ? -1 : (nontemporal & 7);
+  if (nontemporal >= 0) {
+    h->c.nt_x = (nontemporal >> 3) & 1;
+    h->c.rev_xr = (nontemporal >> 4) & 1;   // experiment bits: sweep direction of the vector phases
+    h->c.rev_d = (nontemporal >> 5) & 1;
+  }
   return MFS_OK;
 }
 
@@ -250,12 +267,12 @@ int mfs_pcg3d_phase_reduce(mfs_pcg3d* h, int which, mfs_stream stream) {
 
 int mfs_pcg3d_phase_update_xr(mfs_pcg3d* h, mfs_stream stream) {
   MFS_REQUIRE(h, "null handle");
-  return core_update_xr(h->c, (hipStream_t)stream);
+  return core_update_xr(h->c, false, (hipStream_t)stream);
 }
 
 int mfs_pcg3d_phase_update_d(mfs_pcg3d* h, mfs_stream stream) {
   MFS_REQUIRE(h, "null handle");
-  return core_update_d(h->c, (hipStream_t)stream);
+  return core_update_d(h->c, false, (hipStream_t)stream);
 }
 
 int mfs_pcg3d_begin_local(mfs_pcg3d* h, double tol, mfs_stream stream) {
@@ -279,13 +296,12 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
 
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
-  for (int64_t i = 0; i < n; ++i) {
+  hipStream_t st = (hipStream_t)stream;
+  for (int64_t i = 0; i < n; ++i) {   // 3 launches per iteration: the dots are folded into their consumers
     int e;
     if ((e = mfs_pcg3d_phase_apply(h, 1, h->Nx - 1, 1, stream))) return e;
-    if ((e = mfs_pcg3d_phase_reduce(h, 0, stream))) return e;
-    if ((e = mfs_pcg3d_phase_update_xr(h, stream))) return e;
-    if ((e = mfs_pcg3d_phase_reduce(h, 1, stream))) return e;
-    if ((e = mfs_pcg3d_phase_update_d(h, stream))) return e;
+    if ((e = core_update_xr(h->c, true, st))) return e;
+    if ((e = core_update_d(h->c, true, st))) return e;
   }
   return MFS_OK;
 }

@@ -33,19 +33,6 @@ namespace mfs {
 constexpr int kApplyBlock = 256;
 constexpr int kXcds = 8;
 
-template <typename T, int N> struct NativeVec { typedef T type __attribute__((ext_vector_type(N))); };
-template <typename T> struct NativeVec<T, 1> { typedef T type __attribute__((ext_vector_type(1))); };
-template <typename T, int N> using vec_t = typename NativeVec<T, N>::type;
-
-template <typename T, int VEC>
-__device__ __forceinline__ vec_t<T, VEC> vload(const T* p) { return *reinterpret_cast<const vec_t<T, VEC>*>(p); }
-template <typename T, int VEC>
-__device__ __forceinline__ vec_t<T, VEC> vload_nt(const T* p) {
-  return __builtin_nontemporal_load(reinterpret_cast<const vec_t<T, VEC>*>(p));
-}
-template <typename T, int VEC>
-__device__ __forceinline__ void vstore(T* p, vec_t<T, VEC> v) { *reinterpret_cast<vec_t<T, VEC>*>(p) = v; }
-
 // One z-vector of the stencil.  zl / zr = v just left / right of the vector,
 // czr = cz just right of it.  `first`/`last`: the vector holds the boundary cell
 // z=0 / z=Nz-1, which is neither computed nor stored (PressureCGSolver3D.py:55-57).
@@ -189,9 +176,11 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
 
     int64_t base = (int64_t)x0 * sx + m;
     vec_t<T, VEC> vm = vload<T, VEC>(v + base - sx), vc = vload<T, VEC>(v + base), vp = vload<T, VEC>(v + base + sx);
-    vec_t<T, VEC> cxm = vload<T, VEC>(cx + base), cxp = vload<T, VEC>(cx + base + sx);
+    vec_t<T, VEC> cxm = vload<T, VEC>(cx + base);
+    vec_t<T, VEC> cxp = (NT & 2) ? vload_nt<T, VEC>(cx + base + sx) : vload<T, VEC>(cx + base + sx);
     vec_t<T, VEC> dg = (NT & 1) ? vload_nt<T, VEC>(diag + base) : vload<T, VEC>(diag + base);
-    vec_t<T, VEC> cym = vload<T, VEC>(cy + base), cyp = vload<T, VEC>(cy + base + Nz);
+    vec_t<T, VEC> cym = (NT & 4) ? vload_nt<T, VEC>(cy + base) : vload<T, VEC>(cy + base);
+    vec_t<T, VEC> cyp = (NT & 4) ? vload_nt<T, VEC>(cy + base + Nz) : vload<T, VEC>(cy + base + Nz);
     vec_t<T, VEC> czm = (NT & 1) ? vload_nt<T, VEC>(cz + base) : vload<T, VEC>(cz + base);
 
     if (LDS) {
@@ -224,10 +213,10 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const int64_t nn = more ? nb : base;                  // plane x+1 (or x again on the last step)
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
       const vec_t<T, VEC> vpp = vload<T, VEC>(v + n2);
-      const vec_t<T, VEC> cxpp = vload<T, VEC>(cx + n2);
+      const vec_t<T, VEC> cxpp = (NT & 2) ? vload_nt<T, VEC>(cx + n2) : vload<T, VEC>(cx + n2);
       const vec_t<T, VEC> dg_n = (NT & 1) ? vload_nt<T, VEC>(diag + nn) : vload<T, VEC>(diag + nn);
-      const vec_t<T, VEC> cym_n = vload<T, VEC>(cy + nn);
-      const vec_t<T, VEC> cyp_n = vload<T, VEC>(cy + nn + Nz);
+      const vec_t<T, VEC> cym_n = (NT & 4) ? vload_nt<T, VEC>(cy + nn) : vload<T, VEC>(cy + nn);
+      const vec_t<T, VEC> cyp_n = (NT & 4) ? vload_nt<T, VEC>(cy + nn + Nz) : vload<T, VEC>(cy + nn + Nz);
       const vec_t<T, VEC> czm_n = (NT & 1) ? vload_nt<T, VEC>(cz + nn) : vload<T, VEC>(cz + nn);
       vec_t<T, VEC> hlo_n = {}, hhi_n = {};                           // halos of plane x+2, published one step later
       if (LDS && hofs < Nz) {

@@ -246,10 +246,8 @@ int mfs_pcg2d_solve(mfs_pcg2d* h, double tol, int64_t max_iter, int64_t check_ev
     const int64_t n = std::min(check_every, max_iter - enq);
     for (int64_t i = 0; i < n; ++i) {
       if ((e = apply2d(h, h->c.d, h->c.q, true, st))) return e;
-      if ((e = core_reduce(h->c, 0, 1, st))) return e;
-      if ((e = core_update_xr(h->c, st))) return e;
-      if ((e = core_reduce(h->c, 1, 1, st))) return e;
-      if ((e = core_update_d(h->c, st))) return e;
+      if ((e = core_update_xr(h->c, true, st))) return e;
+      if ((e = core_update_d(h->c, true, st))) return e;
     }
     enq += n;
     if ((e = core_poll(h->c, st, &iters, &done, nullptr, nullptr, nullptr))) return e;

@@ -526,10 +526,8 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
     int e, np = 0;
     if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, st, &np))) return e;   // :589
     h->c.n_part_dq = np;
-    if ((e = core_reduce(h->c, 0, 1, st))) return e;                                  // :592
-    if ((e = core_update_xr(h->c, st))) return e;                                     // :594-601
-    if ((e = core_reduce(h->c, 1, 1, st))) return e;                                  // :604
-    if ((e = core_update_d(h->c, st))) return e;                                      // :605-610
+    if ((e = core_update_xr(h->c, true, st))) return e;                               // :592-601
+    if ((e = core_update_d(h->c, true, st))) return e;                                // :604-610
   }
   return MFS_OK;
 }
