@@ -199,53 +199,106 @@ k_vcg_setup(int Nx, int Ny, int Nz, const void* sphi, int sdt, const void* vol, 
 template <typename T>
 struct Vec3T { const T* p[3]; };
 
-// per-iteration operator row on the compact arrays; also d.q partials.
-template <typename T, int AXIS>
+struct Box3 { int lo[3], hi[3]; };   // face-index box [lo, hi) of one row
+
+// One operator row at face (x,y,z) on the compact arrays.  All loads are
+// unconditional (no load depends on a mask value), so the ~40 loads of a face are
+// in flight together.  MASK=false drops the tap masks: in the CG the operand is
+// `d`, which is exactly 0 on solid and array-boundary faces, so they cannot matter;
+// the initial q = A x (x = extrapolated velocity, non-zero on solid faces) and the
+// stand-alone apply use MASK=true.  The row's OWN mask (solid face -> out = 0) always applies.
+template <typename T, int AXIS, bool MASK>
+__device__ __forceinline__ double vcg_row(const Compact& c, double k1, double k2, const Vec3T<T>& v, int x, int y,
+                                          int z, double& own_out) {
+  const int s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
+  const int64_t f = ((int64_t)x * s1 + y) * s2 + z;
+  double vs[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int ax = kD0[AXIS][0] + kVolOff[k][0], ay = kD0[AXIS][1] + kVolOff[k][1], az = kD0[AXIS][2] + kVolOff[k][2];
+    const int p = ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1);
+    const int e1 = c.N[1] + ((ay & 1) ? 0 : 1), e2 = c.N[2] + ((az & 1) ? 0 : 1);
+    vs[k] = (double)((const T*)c.vol[p])[((int64_t)(x + fdiv2(ax)) * e1 + (y + fdiv2(ay))) * e2 + (z + fdiv2(az))];
+  }
+  const double own = (double)v.p[AXIS][f];
+  const bool own_ok = c.msk[face_class(AXIS)][f] != 0;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double t = kDiagFac[AXIS][k] == 2 ? 2 * vs[k + 1] : vs[k + 1];
+    s = k == 0 ? t : s + t;
+  }
+  double val = (vs[0] + k1 * s) * own;
+#pragma unroll
+  for (int t = 0; t < 14; ++t) {
+    const VTap tp = kTaps[AXIS][t];
+    const int cs1 = c.N[1] + (tp.comp == 1), cs2 = c.N[2] + (tp.comp == 2);
+    const int64_t nb = ((int64_t)(x + tp.dx) * cs1 + (y + tp.dy)) * cs2 + (z + tp.dz);
+    double nbv = (double)v.p[tp.comp][nb];
+    // the tap's mask sample is the validity of the tapped face itself (see header)
+    if (MASK) nbv = c.msk[face_class(tp.comp)][nb] ? nbv : 0.0;
+    val += tp.sgn * ((tp.fac == 2 ? k2 : k1) * vs[tp.vol] * nbv);
+  }
+  own_out = own;
+  return own_ok ? val : 0.0;
+}
+
+// rows of ONE component over a box of faces (used for the three boundary slabs the
+// fused kernel does not cover, and as the simple reference form)
+template <typename T, int AXIS, bool MASK>
 __global__ void __launch_bounds__(256)
-k_vcg_apply(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ out, double* __restrict__ partial,
-            const double* __restrict__ done_flag) {
+k_vcg_apply_row(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ out, Box3 bx, double* __restrict__ partial,
+                const double* __restrict__ done_flag) {
   if (done_flag && *done_flag != 0.0) return;
-  const int s0 = c.N[0] + (AXIS == 0), s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
-  const int i0 = s0 - 2, i1 = s1 - 2, i2 = s2 - 2;                       // interior extents
+  const int s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
+  const int i0 = bx.hi[0] - bx.lo[0], i1 = bx.hi[1] - bx.lo[1], i2 = bx.hi[2] - bx.lo[2];
   const int64_t nint = (int64_t)i0 * i1 * i2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const unsigned char* own_mask = c.msk[face_class(AXIS)];
   double acc = 0.0;
   for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nint; it += stride) {
-    const int z = 1 + (int)(it % i2), y = 1 + (int)((it / i2) % i1), x = 1 + (int)(it / ((int64_t)i2 * i1));
-    const int64_t f = ((int64_t)x * s1 + y) * s2 + z;
-    double val = 0.0;
-    if (own_mask[f]) {
-      double vs[7];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int ax = kD0[AXIS][0] + kVolOff[k][0], ay = kD0[AXIS][1] + kVolOff[k][1], az = kD0[AXIS][2] + kVolOff[k][2];
-        const int p = ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1);
-        const int e1 = c.N[1] + ((ay & 1) ? 0 : 1), e2 = c.N[2] + ((az & 1) ? 0 : 1);
-        vs[k] = (double)((const T*)c.vol[p])[((int64_t)(x + fdiv2(ax)) * e1 + (y + fdiv2(ay))) * e2 + (z + fdiv2(az))];
-      }
-      const double own = (double)v.p[AXIS][f];
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double t = kDiagFac[AXIS][k] == 2 ? 2 * vs[k + 1] : vs[k + 1];
-        s = k == 0 ? t : s + t;
-      }
-      val = (vs[0] + k1 * s) * own;
-#pragma unroll
-      for (int t = 0; t < 14; ++t) {
-        const VTap tp = kTaps[AXIS][t];
-        const int cs1 = c.N[1] + (tp.comp == 1), cs2 = c.N[2] + (tp.comp == 2);
-        const int64_t nb = ((int64_t)(x + tp.dx) * cs1 + (y + tp.dy)) * cs2 + (z + tp.dz);
-        // the tap's mask sample is the validity of the tapped face itself (see header)
-        if (c.msk[face_class(tp.comp)][nb]) {
-          const double term = (tp.fac == 2 ? k2 : k1) * vs[tp.vol] * (double)v.p[tp.comp][nb];
-          val += tp.sgn * term;
-        }
-      }
-      acc += own * (double)(T)val;
+    const int z = bx.lo[2] + (int)(it % i2), y = bx.lo[1] + (int)((it / i2) % i1), x = bx.lo[0] + (int)(it / ((int64_t)i2 * i1));
+    double own;
+    const double val = vcg_row<T, AXIS, MASK>(c, k1, k2, v, x, y, z, own);
+    const T o = (T)val;
+    out[((int64_t)x * s1 + y) * s2 + z] = o;
+    acc += own * (double)o;
+  }
+  const double tot = block_sum<256>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// The per-iteration kernel: all three rows of cell (x,y,z) by one thread, over the
+// box x in [1,Nx-2], y in [1,Ny-2], z in [1,Nz-2] where every row is an interior
+// face.  The three rows share most of their operands (27 distinct velocity and 16
+// distinct volume samples instead of 45 + 21); written from the one tap table, the
+// duplicates are merged by the compiler (all inputs are read-only __restrict__).
+// Lanes run along z (coalesced rows), 4 rows of y per workgroup, marching over a
+// chunk of x planes so the x-1 / x+1 operands are L1/L2 hits of the previous step.
+template <typename T, bool MASK>
+__global__ void __launch_bounds__(256)
+k_vcg_apply_fused(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy,
+                  T* __restrict__ oz, int xchunk, int nbz, int nby, double* __restrict__ partial,
+                  const double* __restrict__ done_flag) {
+  if (done_flag && *done_flag != 0.0) return;
+  const int Nx = c.N[0], Ny = c.N[1], Nz = c.N[2];
+  const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bxk = blockIdx.x / (nbz * nby);
+  const int zr = 1 + bz * 64 + (threadIdx.x & 63), yr = 1 + by * 4 + (threadIdx.x >> 6);
+  const bool active = zr <= Nz - 2 && yr <= Ny - 2;
+  const int z = min(zr, Nz - 2), y = min(yr, Ny - 2);      // inactive lanes recompute a valid cell, store nothing
+  const int x0 = 1 + bxk * xchunk, x1 = min(x0 + xchunk, Nx - 1);
+  double acc = 0.0;
+  for (int x = x0; x < x1; ++x) {
+    double o0, o1, o2;
+    const double r0 = vcg_row<T, 0, MASK>(c, k1, k2, v, x, y, z, o0);
+    const double r1 = vcg_row<T, 1, MASK>(c, k1, k2, v, x, y, z, o1);
+    const double r2 = vcg_row<T, 2, MASK>(c, k1, k2, v, x, y, z, o2);
+    if (active) {
+      const T t0 = (T)r0, t1 = (T)r1, t2 = (T)r2;
+      ox[((int64_t)x * Ny + y) * Nz + z] = t0;
+      oy[((int64_t)x * (Ny + 1) + y) * Nz + z] = t1;
+      oz[((int64_t)x * Ny + y) * (Nz + 1) + z] = t2;
+      acc += o0 * (double)t0 + o1 * (double)t1 + o2 * (double)t2;
     }
-    out[f] = (T)val;
   }
   const double tot = block_sum<256>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -266,6 +319,7 @@ struct mfs_vcg3d {
   double k1, k2;
   bool is_setup;
   int grid_row;
+  int mask_cg;   // 1: keep the tap masks in CG applies too (debug / A-B)
 };
 
 static int64_t class_count(const int64_t gres[3], int p) {
@@ -305,38 +359,66 @@ static int launch_rows_direct(const int64_t gres[3], double scale, double mu, co
   return MFS_OK;
 }
 
-template <typename T>
-static int vcg_apply_T(mfs_vcg3d* h, const void* v, void* out, double* partial, const double* done, hipStream_t st,
-                       int* nparts) {
+template <typename T, bool MASK>
+static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial, const double* done, hipStream_t st,
+                        int* nparts) {
   const T* vb = (const T*)v;
   T* ob = (T*)out;
   Vec3T<T> vv{{vb + h->off[0], vb + h->off[1], vb + h->off[2]}};
+  const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   int used = 0;
-  auto grid_for = [&](int ax) {
-    const int64_t nint = (int64_t)(h->g.sh(ax, 0) - 2) * (h->g.sh(ax, 1) - 2) * (h->g.sh(ax, 2) - 2);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(h->grid_row, (nint + 255) / 256));
+  // (1) the box where all three rows are interior faces: one fused launch
+  if (Nx >= 3 && Ny >= 3 && Nz >= 3) {
+    const int nbz = (Nz - 2 + 63) / 64, nby = (Ny - 2 + 3) / 4;
+    int xchunk = 8;
+    while ((int64_t)nbz * nby * ((Nx - 2 + xchunk - 1) / xchunk) > 4096) xchunk *= 2;
+    const int grid = nbz * nby * ((Nx - 2 + xchunk - 1) / xchunk);
+    hipLaunchKernelGGL((k_vcg_apply_fused<T, MASK>), dim3(grid), dim3(256), 0, st, h->cp, h->k1, h->k2, vv,
+                       ob + h->off[0], ob + h->off[1], ob + h->off[2], xchunk, nbz, nby, partial + used, done);
+    used += grid;
+  }
+  // (2) the three slabs of interior faces outside that box: u at x = Nx-1, v at y = Ny-1, w at z = Nz-1
+  auto slab = [&](int ax) {
+    Box3 b;
+    for (int a = 0; a < 3; ++a) { b.lo[a] = 1; b.hi[a] = h->g.sh(ax, a) - 1; }
+    b.lo[ax] = h->g.N[ax] - 1;
+    b.hi[ax] = h->g.N[ax];
+    return b;
   };
-  const int g0 = grid_for(0), g1 = grid_for(1), g2 = grid_for(2);
-  hipLaunchKernelGGL((k_vcg_apply<T, 0>), dim3(g0), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[0],
-                     partial + used, done);
-  used += g0;
-  hipLaunchKernelGGL((k_vcg_apply<T, 1>), dim3(g1), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[1],
-                     partial + used, done);
-  used += g1;
-  hipLaunchKernelGGL((k_vcg_apply<T, 2>), dim3(g2), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[2],
-                     partial + used, done);
-  used += g2;
+  auto sgrid = [&](const Box3& b) {
+    const int64_t n = (int64_t)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(256, (n + 255) / 256));
+  };
+  if (Nx >= 2 && Ny >= 3 && Nz >= 3) {
+    const Box3 b = slab(0); const int g = sgrid(b);
+    hipLaunchKernelGGL((k_vcg_apply_row<T, 0, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[0], b, partial + used, done);
+    used += g;
+  }
+  if (Nx >= 3 && Ny >= 2 && Nz >= 3) {
+    const Box3 b = slab(1); const int g = sgrid(b);
+    hipLaunchKernelGGL((k_vcg_apply_row<T, 1, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[1], b, partial + used, done);
+    used += g;
+  }
+  if (Nx >= 3 && Ny >= 3 && Nz >= 2) {
+    const Box3 b = slab(2); const int g = sgrid(b);
+    hipLaunchKernelGGL((k_vcg_apply_row<T, 2, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[2], b, partial + used, done);
+    used += g;
+  }
   MFS_LAUNCH_CHECK();
   *nparts = used;
   return MFS_OK;
 }
 
-static int vcg_apply(mfs_vcg3d* h, const void* v, void* out, double* partial, bool use_done, hipStream_t st,
-                     int* nparts) {
+// masked = false only for operands that are 0 on solid / array-boundary faces (the CG's d)
+static int vcg_apply(mfs_vcg3d* h, const void* v, void* out, double* partial, bool use_done, bool masked,
+                     hipStream_t st, int* nparts) {
   if (h->g.N[0] < 2 || h->g.N[1] < 2 || h->g.N[2] < 2) { *nparts = 0; return MFS_OK; }
   const double* done = use_done ? h->c.scal + S_DONE : nullptr;
-  return h->dt == MFS_F32 ? vcg_apply_T<float>(h, v, out, partial, done, st, nparts)
-                          : vcg_apply_T<double>(h, v, out, partial, done, st, nparts);
+  if (h->dt == MFS_F32)
+    return masked ? vcg_apply_TM<float, true>(h, v, out, partial, done, st, nparts)
+                  : vcg_apply_TM<float, false>(h, v, out, partial, done, st, nparts);
+  return masked ? vcg_apply_TM<double, true>(h, v, out, partial, done, st, nparts)
+                : vcg_apply_TM<double, false>(h, v, out, partial, done, st, nparts);
 }
 
 extern "C" {
@@ -454,6 +536,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   for (int q : {3, 5, 6}) { h->cp.msk[q] = (unsigned char*)p; p += align_up((size_t)class_count(gres, q), 4096); }
   h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
   h->is_setup = false;
+  h->mask_cg = env_int("MFS_VISC_MASK_CG", 0);
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
     set_error("hipMemsetAsync(workspace) failed");
@@ -499,7 +582,7 @@ int mfs_vcg3d_apply(mfs_vcg3d* h, const void* v, void* out, mfs_stream stream) {
   MFS_REQUIRE(h && v && out && v != out, "null / aliased argument");
   MFS_REQUIRE(h->is_setup, "mfs_vcg3d_setup has not been called");
   int np = 0;
-  if (int e = vcg_apply(h, v, out, h->c.part_dq, false, (hipStream_t)stream, &np)) return e;
+  if (int e = vcg_apply(h, v, out, h->c.part_dq, false, true, (hipStream_t)stream, &np)) return e;
   h->c.n_part_dq = np;
   return MFS_OK;
 }
@@ -514,7 +597,7 @@ int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;     // x keeps the extrapolated velocity (:569-573)
   int np = 0;
-  if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, st, &np)) return e;   // :575
+  if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;   // :575
   if (int e = core_begin_post(h->c, st)) return e;                // :577-585
   return core_begin_finish(h->c, st);
 }
@@ -524,7 +607,7 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   for (int64_t i = 0; i < n; ++i) {
     int e, np = 0;
-    if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, st, &np))) return e;   // :589
+    if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;   // :589
     h->c.n_part_dq = np;
     if ((e = core_update_xr(h->c, true, st))) return e;                               // :592-601
     if ((e = core_update_d(h->c, true, st))) return e;                                // :604-610

@@ -150,6 +150,11 @@ def test_solve_fp64_vs_golden(mods, name):
     for a, k in ((vx, "out_vx"), (vy, "out_vy"), (vz, "out_vz")):
         assert a.dtype == torch.as_tensor(g[k]).dtype
         close(a, g[k], max(vtol, 2e-7 if a.dtype == torch.float32 else 0), k)
+    # the reference's stopping rule, re-evaluated with the ORACLE operator on the GPU's solution
+    q = np.zeros(gres)
+    O.pressure_apply3d(gres, s.x.cpu().numpy(), q, g["wx"], g["wy"], g["wz"], g["lphi"])
+    true_delta = float(((g["b"] - q) ** 2).sum())
+    assert true_delta < 1.01 * float(g["tol"]) ** 2, true_delta
     # caller-supplied weights (the notebook passes DensitySolver.wx, ipynb:4648): same result
     buf2 = B.CGSolverBuffer(gres, precision="fp64", device=DEV)
     s2 = P.PressureCGSolver3D(buf2, gres, g["bound_size"])

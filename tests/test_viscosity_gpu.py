@@ -98,18 +98,35 @@ def test_solve_vs_golden(V, name, prec):
     s.solve(float(g["dt"]), float(g["mu"]), float(g["rho"]), vx, vy, vz, T(g["sphi"]), T(g["sv"]), T(g["lphi"]),
             T(g["lvol"]), tol=float(g["tol"]))
     it = int(g["iters"])
+    # mu = 1 cases are well conditioned (the oracle's history is insensitive to rounding: 1e-15 under a
+    # reversed summation order); the mu = 50 case is rounding-chaotic like the pressure pool scenes
+    # (its oracle history moves by 0.7 under the same perturbation) -> leading window + field check
+    # at the accuracy the stopping rule itself defines, plus the reference's stopping rule re-evaluated
+    # with the ORACLE operator on the GPU's solution.
+    stable = "mu50" not in name
     if prec == "fp64":
         hist_window(s.history, g["history"], 10, 1e-9)
-        assert abs(s.iterations - it) <= max(2, it // 10)
+        if stable:
+            assert s.iterations == it
+            np.testing.assert_allclose(s.history, g["history"], rtol=1e-9)
+        else:
+            assert abs(s.iterations - it) <= max(2, it // 10)
     else:
         hist_window(s.history, g["history"], 8, 1e-5)
         assert 0.8 * it - 2 <= s.iterations <= 1.5 * it + 2
     assert s.delta < float(g["tol"]) ** 2 and s.delta == s.history[-1]
-    for a, k in ((s.x_x, "x_x"), (s.x_y, "x_y"), (s.x_z, "x_z")):
-        close(a, g[k], 1e-4, k)
+    vscale = max(np.abs(g[k]).max() for k in ("x_x", "x_y", "x_z"))
+    ftol = (1e-10 if prec == "fp64" else 2e-5) if stable else 1e-3
+    for a, k in ((s.x_x, "x_x"), (s.x_y, "x_y"), (s.x_z, "x_z"), (vx, "out_vx"), (vy, "out_vy"), (vz, "out_vz")):
+        np.testing.assert_allclose(a.cpu().numpy().astype(np.float64), g[k], rtol=0, atol=ftol * vscale, err_msg=k)
+    if prec == "fp64":   # true residual of the GPU solution under the oracle's operator meets the stopping rule
+        scale, mu, vol = _params(g)
+        q = [np.zeros_like(g[k]) for k in ("bx", "by", "bz")]
+        O.visc_apply3d(gres, scale, mu, *[t.cpu().numpy() for t in (s.x_x, s.x_y, s.x_z)], *q, g["sphi"], vol)
+        true_delta = sum(float(((g[k] - qq) ** 2).sum()) for k, qq in zip(("bx", "by", "bz"), q))
+        assert true_delta < 1.01 * float(g["tol"]) ** 2, true_delta
     for a, k in ((vx, "out_vx"), (vy, "out_vy"), (vz, "out_vz")):
         assert a.dtype == torch.as_tensor(g[k]).dtype
-        close(a, g[k], 1e-4, k)
     close(s.vol, g["lvol"] / (float(np.prod(g["bound_size"] / g["gres"])) * 0.125), 1e-15, "vol")
 
 
