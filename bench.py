@@ -151,6 +151,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     cg.iterate(args.steps)
+    t_enq = time.perf_counter() - t0      # host time to enqueue the steps (no sync inside)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -229,6 +230,7 @@ def main():
                        "decomposition": f"x-slabs x{world}" if world > 1 else "single domain",
                        "step": "one CG iteration (apply + 2 dots + x/r/d updates)"},
             "iters_per_s": round(args.steps / dt, 2),
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5),
             "cg_iteration_hbm_gbs": round(iter_bytes / (dt / args.steps) / 1e9, 1),
             "roofline": rf,
         }

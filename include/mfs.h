@@ -122,10 +122,18 @@ int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_strea
 /* -- single phases of one iteration, for the slab-decomposed multi-GPU driver.
  * Order per iteration k:  [halo exchange of d] phase_apply(ranges...) ->
  * phase_reduce(0) -> [all-reduce scalars[DQ]] -> phase_update_xr ->
- * phase_reduce(1) -> [all-reduce scalars[RR]] -> phase_update_d.               */
+ * phase_reduce(1) -> [all-reduce scalars[RR]] -> phase_update_d
+ * (or phase_update_r -> phase_reduce(1) -> [all-reduce RR || phase_update_x] -> phase_update_d). */
 int mfs_pcg3d_phase_apply(mfs_pcg3d* h, int64_t x_begin, int64_t x_end, int first, mfs_stream stream);
+/* two disjoint plane ranges in one launch (the driver's two edge planes) */
+int mfs_pcg3d_phase_apply2(mfs_pcg3d* h, int64_t x_begin, int64_t x_end, int64_t x_begin2, int64_t x_end2,
+                           int first, mfs_stream stream);
 int mfs_pcg3d_phase_reduce(mfs_pcg3d* h, int which, mfs_stream stream);
 int mfs_pcg3d_phase_update_xr(mfs_pcg3d* h, mfs_stream stream);
+/* the same update as two kernels: `r -= a q` (+ r.r partials) and `x += a d`, so that the
+ * driver can start the r.r all-reduce after the first and overlap it with the second */
+int mfs_pcg3d_phase_update_r(mfs_pcg3d* h, mfs_stream stream);
+int mfs_pcg3d_phase_update_x(mfs_pcg3d* h, mfs_stream stream);
 int mfs_pcg3d_phase_update_d(mfs_pcg3d* h, mfs_stream stream);
 /* begin, split around the one reduction it contains: begin_local -> [all-reduce RR] -> begin_finish */
 int mfs_pcg3d_begin_local(mfs_pcg3d* h, double tol, mfs_stream stream);

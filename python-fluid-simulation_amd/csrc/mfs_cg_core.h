@@ -102,7 +102,9 @@ __device__ __forceinline__ double block_total_of(const double* __restrict__ part
 // alpha = delta / dq ; x += alpha d ; r -= alpha q ; partial sum r^2   (:211-216)
 // NTX: x is touched once per iteration and by no other kernel -> stream it past the
 // caches (nontemporal load + store) so that d, r, q keep their Infinity-Cache lines.
-template <typename T, int VEC, bool NTX>
+// MODE 0: both updates in one pass (one GPU).  MODE 1: r only (+ partials), MODE 2: x only --
+// the multi-GPU driver runs them as two kernels so that the x update overlaps the r.r all-reduce.
+template <typename T, int VEC, bool NTX, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
             double* __restrict__ scal, double* __restrict__ partial, int rev, int par,
@@ -115,26 +117,36 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
   double acc = 0.0;
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
     if (vec) {
-      vec_t<T, VEC> xv = NTX ? vload_nt<T, VEC>(x + i) : vload<T, VEC>(x + i);
-      vec_t<T, VEC> rv = vload<T, VEC>(r + i);
-      const vec_t<T, VEC> dv = vload<T, VEC>(d + i), qv = vload<T, VEC>(q + i);
+      if (MODE != 1) {
+        vec_t<T, VEC> xv = NTX ? vload_nt<T, VEC>(x + i) : vload<T, VEC>(x + i);
+        const vec_t<T, VEC> dv = vload<T, VEC>(d + i);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
-        rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
-        acc += (double)rv[j] * (double)rv[j];
+        for (int j = 0; j < VEC; ++j) xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
+        if (NTX) vstore_nt<T, VEC>(x + i, xv); else vstore<T, VEC>(x + i, xv);
       }
-      if (NTX) vstore_nt<T, VEC>(x + i, xv); else vstore<T, VEC>(x + i, xv);
-      vstore<T, VEC>(r + i, rv);
+      if (MODE != 2) {
+        vec_t<T, VEC> rv = vload<T, VEC>(r + i);
+        const vec_t<T, VEC> qv = vload<T, VEC>(q + i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
+          acc += (double)rv[j] * (double)rv[j];
+        }
+        vstore<T, VEC>(r + i, rv);
+      }
     } else {
-      const T xn = (T)((double)x[i] + alpha * (double)d[i]);
-      const T rn = (T)((double)r[i] - alpha * (double)q[i]);
-      x[i] = xn; r[i] = rn;
-      acc += (double)rn * (double)rn;
+      if (MODE != 1) x[i] = (T)((double)x[i] + alpha * (double)d[i]);
+      if (MODE != 2) {
+        const T rn = (T)((double)r[i] - alpha * (double)q[i]);
+        r[i] = rn;
+        acc += (double)rn * (double)rn;
+      }
     }
   }, rev != 0);
-  const double tot = block_sum<kBlock>(acc);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  if (MODE != 2) {
+    const double tot = block_sum<kBlock>(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  }
 }
 
 // convergence test (:218), bookkeeping, beta (:220), d = r + beta d (:221)
@@ -300,23 +312,28 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
   return MFS_OK;
 }
 
-#define MFS_XR(TT, VV, NN) \
-  hipLaunchKernelGGL((k_update_xr<TT, VV, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x, (const TT*)c.d, (TT*)c.r, \
-                     (const TT*)c.q, c.n, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), c.part_dq, fold ? c.n_part_dq : 0)
-static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st) {
+#define MFS_XR(TT, VV, NN, MM) \
+  hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x, (const TT*)c.d, \
+                     (TT*)c.r, (const TT*)c.q, c.n, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), c.part_dq, \
+                     fold ? c.n_part_dq : 0)
+#define MFS_XR_MODE(MM)                                                                                              \
+  if (c.dt == MFS_F32) {                                                                                             \
+    if (!vec) MFS_XR(float, 1, false, MM); else if (ntx) MFS_XR(float, 4, true, MM); else MFS_XR(float, 4, false, MM); \
+  } else {                                                                                                           \
+    if (!vec) MFS_XR(double, 1, false, MM); else if (ntx) MFS_XR(double, 2, true, MM); else MFS_XR(double, 2, false, MM); \
+  }
+// mode 0: x and r together; 1: r only (+ r.r partials); 2: x only
+static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode = 0) {
   MFS_REQUIRE(c.x, "engine not bound");
   const bool vec = core_vec_ok(c);
   const int grid = core_vec_grid(c, vec);
   const bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
-  if (c.dt == MFS_F32) {
-    if (!vec) MFS_XR(float, 1, false); else if (ntx) MFS_XR(float, 4, true); else MFS_XR(float, 4, false);
-  } else {
-    if (!vec) MFS_XR(double, 1, false); else if (ntx) MFS_XR(double, 2, true); else MFS_XR(double, 2, false);
-  }
+  if (mode == 1) { MFS_XR_MODE(1) } else if (mode == 2) { MFS_XR_MODE(2) } else { MFS_XR_MODE(0) }
   MFS_LAUNCH_CHECK();
-  c.n_part_rr = grid;
+  if (mode != 2) c.n_part_rr = grid;
   return MFS_OK;
 }
+#undef MFS_XR_MODE
 #undef MFS_XR
 
 static inline int core_update_d(CgCore& c, bool fold, hipStream_t st) {

@@ -79,8 +79,8 @@ struct mfs_pcg3d {
 static size_t coef_stride(int64_t n, size_t elt) { return align_up((size_t)n * elt, 4096) + 4096 * 3 + 256; }
 
 template <typename T, int VEC>
-static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, double* partial, const double* done,
-                          hipStream_t st, int* grid_out) {
+static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int xb2, int xe2, double* partial,
+                          const double* done, hipStream_t st, int* grid_out) {
   const T *dg = (const T*)h->diag, *cx = (const T*)h->cx, *cy = (const T*)h->cy, *cz = (const T*)h->cz;
   const int nzv = h->Nz / VEC;
   const int64_t ipp = (int64_t)(h->Ny - 2) * nzv;
@@ -88,16 +88,17 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, doub
   const size_t lds = 2 * ((size_t)kApplyBlock * VEC + 2 * (size_t)h->Nz) * sizeof(T);
   if (variant == 2 && lds > 64 * 1024) variant = 1;          // absurdly long rows: skip the LDS image
   const int xchunk = std::max(0, h->xchunk);   // 0 = no cap on the length of one march
-  ApplyArgs a{h->Nx, h->Ny, h->Nz, xb, xe, xchunk};
+  ApplyArgs a{h->Nx, h->Ny, h->Nz, xb, xe, xchunk, xb2, xe2};
+  const int np = (xe - xb) + (xe2 - xb2);
   if (variant == 0) {
-    const int64_t items = (int64_t)(xe - xb) * ipp;
+    const int64_t items = (int64_t)np * ipp;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->grid_apply, (items + kApplyBlock - 1) / kApplyBlock));
     hipLaunchKernelGGL((k_pcg_apply_direct<T, VEC>), dim3(grid), dim3(kApplyBlock), 0, st, v, out, dg, cx, cy, cz, a,
                        partial, done);
     *grid_out = grid;
   } else {
     const int64_t tiles = (ipp + kApplyBlock - 1) / kApplyBlock;
-    const int64_t total = tiles * (xe - xb);                 // (tile, plane) pairs, cut into `grid` equal segments
+    const int64_t total = tiles * np;                 // (tile, plane) pairs, cut into `grid` equal segments
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kMaxPartials, h->cus * h->bpc), total));
     // Nontemporal loads for the once-read coefficient streams pay off only when the
     // apply's working set (6 arrays) cannot sit in the 256 MiB Infinity Cache anyway;
@@ -127,22 +128,26 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, doub
 }
 
 template <typename T>
-static int launch_apply(mfs_pcg3d* h, const void* v, void* out, int xb, int xe, double* partial, int use_done,
-                        hipStream_t st, int* grid_out) {
-  if (xe - xb <= 0) { *grid_out = 0; return MFS_OK; }
+static int launch_apply(mfs_pcg3d* h, const void* v, void* out, int xb, int xe, int xb2, int xe2, double* partial,
+                        int use_done, hipStream_t st, int* grid_out) {
+  if (xe < xb) xe = xb;
+  if (xe2 < xb2) xe2 = xb2;
+  if ((xe - xb) + (xe2 - xb2) <= 0) { *grid_out = 0; return MFS_OK; }
   constexpr int VEC = VecOf<T>::N;
   const bool vec = h->vec_ok && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 16 == 0);
   const double* done = use_done ? h->c.scal + S_DONE : nullptr;
-  if (vec) return launch_apply_v<T, VEC>(h, (const T*)v, (T*)out, xb, xe, partial, done, st, grid_out);
-  return launch_apply_v<T, 1>(h, (const T*)v, (T*)out, xb, xe, partial, done, st, grid_out);
+  if (vec) return launch_apply_v<T, VEC>(h, (const T*)v, (T*)out, xb, xe, xb2, xe2, partial, done, st, grid_out);
+  return launch_apply_v<T, 1>(h, (const T*)v, (T*)out, xb, xe, xb2, xe2, partial, done, st, grid_out);
 }
 
 static int apply_dispatch(mfs_pcg3d* h, const void* v, void* out, int64_t xb, int64_t xe, double* partial,
-                          int use_done, hipStream_t st, int* grid_out) {
-  const int b = (int)std::max<int64_t>(xb, 1), e = (int)std::min<int64_t>(xe, h->Nx - 1);
+                          int use_done, hipStream_t st, int* grid_out, int64_t xb2 = 0, int64_t xe2 = 0) {
+  const int lo = 1, hi = h->Nx - 1;
+  auto clip = [&](int64_t v_) { return (int)std::max<int64_t>(lo, std::min<int64_t>(hi, v_)); };
   if (h->Ny < 3 || h->Nz < 3) { *grid_out = 0; return MFS_OK; }
-  return h->dt == MFS_F32 ? launch_apply<float>(h, v, out, b, e, partial, use_done, st, grid_out)
-                          : launch_apply<double>(h, v, out, b, e, partial, use_done, st, grid_out);
+  const int b = clip(xb), e = clip(xe), b2 = clip(xb2), e2 = xe2 > xb2 ? clip(xe2) : b2;
+  return h->dt == MFS_F32 ? launch_apply<float>(h, v, out, b, e, b2, e2, partial, use_done, st, grid_out)
+                          : launch_apply<double>(h, v, out, b, e, b2, e2, partial, use_done, st, grid_out);
 }
 
 extern "C" {
@@ -259,6 +264,21 @@ int mfs_pcg3d_phase_apply(mfs_pcg3d* h, int64_t x_begin, int64_t x_end, int firs
   return MFS_OK;
 }
 
+int mfs_pcg3d_phase_apply2(mfs_pcg3d* h, int64_t x_begin, int64_t x_end, int64_t x_begin2, int64_t x_end2, int first,
+                           mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.d && h->is_setup, "engine not bound / set up");
+  MFS_REQUIRE(x_end <= x_begin2 || x_end2 <= x_begin, "the two plane ranges must not overlap");
+  if (first) h->c.n_part_dq = 0;
+  MFS_REQUIRE(h->c.n_part_dq + std::max(h->grid_apply, h->cus * h->bpc) <= kMaxPartials,
+              "too many apply ranges in one iteration");
+  int grid = 0;
+  if (int e = apply_dispatch(h, h->c.d, h->c.q, x_begin, x_end, h->c.part_dq + h->c.n_part_dq, 1,
+                             (hipStream_t)stream, &grid, x_begin2, x_end2))
+    return e;
+  h->c.n_part_dq += grid;
+  return MFS_OK;
+}
+
 int mfs_pcg3d_phase_reduce(mfs_pcg3d* h, int which, mfs_stream stream) {
   MFS_REQUIRE(h, "null handle");
   MFS_REQUIRE(which == 0 || which == 1, "which must be 0 (d.q) or 1 (r.r)");
@@ -268,6 +288,16 @@ int mfs_pcg3d_phase_reduce(mfs_pcg3d* h, int which, mfs_stream stream) {
 int mfs_pcg3d_phase_update_xr(mfs_pcg3d* h, mfs_stream stream) {
   MFS_REQUIRE(h, "null handle");
   return core_update_xr(h->c, false, (hipStream_t)stream);
+}
+
+int mfs_pcg3d_phase_update_r(mfs_pcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  return core_update_xr(h->c, false, (hipStream_t)stream, 1);
+}
+
+int mfs_pcg3d_phase_update_x(mfs_pcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  return core_update_xr(h->c, false, (hipStream_t)stream, 2);
 }
 
 int mfs_pcg3d_phase_update_d(mfs_pcg3d* h, mfs_stream stream) {

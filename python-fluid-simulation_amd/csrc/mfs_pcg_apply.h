@@ -72,8 +72,10 @@ __device__ __forceinline__ void stencil_vec(T* __restrict__ out_ptr, vec_t<T, VE
   }
 }
 
+// planes [xb, xe) and, optionally, a second range [xb2, xe2) handled by the same launch
+// (the multi-GPU driver applies its two edge planes {1, L-2} in one launch)
 struct ApplyArgs {
-  int Nx, Ny, Nz, xb, xe, xchunk;
+  int Nx, Ny, Nz, xb, xe, xchunk, xb2, xe2;
 };
 
 // ------------------------------------------------------------- variant 0 ----
@@ -88,7 +90,8 @@ k_pcg_apply_direct(const T* __restrict__ v, T* __restrict__ out, const T* __rest
   if (done_flag && *done_flag != 0.0) return;
   const int nzv = a.Nz / VEC;
   const int64_t ipp = (int64_t)(a.Ny - 2) * nzv;
-  const int np = a.xe - a.xb;
+  const int n1 = a.xe - a.xb;
+  const int np = n1 + (a.xe2 - a.xb2);
   const int nch = min((int)gridDim.x, kXcds);
   const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
   const int nblk = (gridDim.x - xcd + nch - 1) / nch;
@@ -100,7 +103,8 @@ k_pcg_apply_direct(const T* __restrict__ v, T* __restrict__ out, const T* __rest
     const int px = (int)(it / ipp);
     const int rem = (int)(it - (int64_t)px * ipp);
     const int yy = rem / nzv, zv = rem - (rem / nzv) * nzv;
-    const int64_t base = (int64_t)(a.xb + px) * sx + (int64_t)(yy + 1) * sy + (int64_t)zv * VEC;
+    const int xx = px < n1 ? a.xb + px : a.xb2 + (px - n1);
+    const int64_t base = (int64_t)xx * sx + (int64_t)(yy + 1) * sy + (int64_t)zv * VEC;
     const bool first = zv == 0, last = zv == nzv - 1;
     const auto vc = vload<T, VEC>(v + base);
     const double zl = first ? 0.0 : (double)v[base - 1];
@@ -136,7 +140,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
   const int nzv = Nz / VEC;
   const int ipp = (a.Ny - 2) * nzv;                         // interior z-vectors per plane
   const int tiles = (ipp + kApplyBlock - 1) / kApplyBlock;
-  const int np = a.xe - a.xb;
+  const int n1 = a.xe - a.xb;
+  const int np = n1 + (a.xe2 - a.xb2);
   // Work = the sequence of (tile, plane) pairs, tile-major.  It is cut into gridDim
   // equal contiguous segments (+-1 pair): every workgroup marches the same number of
   // planes, so all CUs finish together whatever the grid shape; a segment that runs
@@ -158,8 +163,9 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
 
   for (int64_t i = s0; i < s1;) {
     const int tile = (int)(i / np);
-    const int x0 = a.xb + (int)(i - (int64_t)tile * np);
-    int len = (int)min((int64_t)(a.xe - x0), s1 - i);
+    const int pl = (int)(i - (int64_t)tile * np);          // plane slot inside the (up to two) ranges
+    const int x0 = pl < n1 ? a.xb + pl : a.xb2 + (pl - n1);
+    int len = (int)min((int64_t)((pl < n1 ? a.xe : a.xe2) - x0), s1 - i);
     if (a.xchunk > 0) len = min(len, a.xchunk);
     const int x1 = x0 + len;
     i += len;

@@ -58,8 +58,11 @@ SIGNATURES = {
     "mfs_pcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
     "mfs_pcg3d_history": (_i64, [_p, _pd, _i64, _p]),
     "mfs_pcg3d_phase_apply": (_i, [_p, _i64, _i64, _i, _p]),
+    "mfs_pcg3d_phase_apply2": (_i, [_p, _i64, _i64, _i64, _i64, _i, _p]),
     "mfs_pcg3d_phase_reduce": (_i, [_p, _i, _p]),
     "mfs_pcg3d_phase_update_xr": (_i, [_p, _p]),
+    "mfs_pcg3d_phase_update_r": (_i, [_p, _p]),
+    "mfs_pcg3d_phase_update_x": (_i, [_p, _p]),
     "mfs_pcg3d_phase_update_d": (_i, [_p, _p]),
     "mfs_pcg3d_begin_local": (_i, [_p, _d, _p]),
     "mfs_pcg3d_begin_finish": (_i, [_p, _p]),

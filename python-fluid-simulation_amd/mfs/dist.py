@@ -99,17 +99,30 @@ class SlabCG:
                 ops.phase_apply(2, L - 2, True)      # planes that touch no ghost, while the halos fly
                 for w in reqs:
                     w.wait()
-                ops.phase_apply(1, 2, False)
-                ops.phase_apply(L - 2, L - 1, False)
+                if hasattr(ops, "phase_apply2"):
+                    ops.phase_apply2(1, 2, L - 2, L - 1, False)      # both edge planes, one launch
+                else:
+                    ops.phase_apply(1, 2, False)
+                    ops.phase_apply(L - 2, L - 1, False)
             else:
                 for w in reqs:
                     w.wait()
                 ops.phase_apply(1, L - 1, True)
             ops.phase_reduce(0)
             self._allreduce(_lib.S_DQ)
-            ops.phase_update_xr()
-            ops.phase_reduce(1)
-            self._allreduce(_lib.S_RR)
+            if self.overlap:
+                # r first, so the r.r all-reduce is in flight (on the collective's own stream)
+                # while x += alpha d runs on the compute stream
+                ops.phase_update_r()
+                ops.phase_reduce(1)
+                work = self.dist.all_reduce(self.ops.scalars[_lib.S_RR:_lib.S_RR + 1], group=self.group,
+                                            async_op=True)
+                ops.phase_update_x()
+                work.wait()
+            else:
+                ops.phase_update_xr()
+                ops.phase_reduce(1)
+                self._allreduce(_lib.S_RR)
             ops.phase_update_d()
 
     def exchange(self, t):

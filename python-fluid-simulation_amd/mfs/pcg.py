@@ -107,11 +107,21 @@ class PcgEngine:
         _lib.check(self.lib.mfs_pcg3d_phase_apply(self.h, int(xb), int(xe), int(bool(first)), T.stream()),
                    "mfs_pcg3d_phase_apply")
 
+    def phase_apply2(self, xb, xe, xb2, xe2, first):
+        _lib.check(self.lib.mfs_pcg3d_phase_apply2(self.h, int(xb), int(xe), int(xb2), int(xe2), int(bool(first)),
+                                                   T.stream()), "mfs_pcg3d_phase_apply2")
+
     def phase_reduce(self, which):
         _lib.check(self.lib.mfs_pcg3d_phase_reduce(self.h, int(which), T.stream()), "mfs_pcg3d_phase_reduce")
 
     def phase_update_xr(self):
         _lib.check(self.lib.mfs_pcg3d_phase_update_xr(self.h, T.stream()), "mfs_pcg3d_phase_update_xr")
+
+    def phase_update_r(self):
+        _lib.check(self.lib.mfs_pcg3d_phase_update_r(self.h, T.stream()), "mfs_pcg3d_phase_update_r")
+
+    def phase_update_x(self):
+        _lib.check(self.lib.mfs_pcg3d_phase_update_x(self.h, T.stream()), "mfs_pcg3d_phase_update_x")
 
     def phase_update_d(self):
         _lib.check(self.lib.mfs_pcg3d_phase_update_d(self.h, T.stream()), "mfs_pcg3d_phase_update_d")

@@ -89,6 +89,18 @@ class OracleSlabOps:
         self.x += alpha * self.d
         self.r -= alpha * self.q
 
+    def phase_update_r(self):
+        if self._done():
+            return
+        alpha = self.scalars[S.S_DELTA].item() / self.scalars[S.S_DQ].item()
+        self.r -= alpha * self.q
+
+    def phase_update_x(self):
+        if self._done():
+            return
+        alpha = self.scalars[S.S_DELTA].item() / self.scalars[S.S_DQ].item()
+        self.x += alpha * self.d
+
     def phase_update_d(self):
         if self._done():
             return
