@@ -114,6 +114,8 @@ def _theta(phi, nphi):
 def pressure_rhs3d(cell_size, gres, vx, vy, vz, sphi, sv, lphi, b, wx, wy, wz):
     """solver/PressureCGSolver3D.py:6-50 (initialize_solver_kernel)."""
     Nx, Ny, Nz = (int(g) for g in gres)
+    if min(Nx, Ny, Nz) < 3:
+        return                       # no interior cell: the kernel's every thread returns at :8-10
     cs = [float(c) for c in cell_size]
     I = (slice(1, Nx - 1), slice(1, Ny - 1), slice(1, Nz - 1))
     sv = np.asarray(sv, F64)
@@ -144,6 +146,8 @@ def pressure_apply3d(gres, v, out, wx, wy, wz, lphi):
     """solver/PressureCGSolver3D.py:52-130 (matvecmul_kernel).  Boundary cells of
     `out` are not written (:55-57); non-fluid interior cells get 0 (:60-63)."""
     Nx, Ny, Nz = (int(g) for g in gres)
+    if min(Nx, Ny, Nz) < 3:
+        return
     I = (slice(1, Nx - 1), slice(1, Ny - 1), slice(1, Nz - 1))
 
     def sh(a, dx, dy, dz):
@@ -450,6 +454,8 @@ def visc_extrapolate3d(gres, num_iter, vx, vy, vz, sphi):
     for _ in range(num_iter):
         for v, valid in zip((vx, vy, vz), valids):
             n = v.shape
+            if min(n) < 3:
+                continue             # no interior face
             I = (slice(1, n[0] - 1), slice(1, n[1] - 1), slice(1, n[2] - 1))
             val = np.zeros(tuple(s - 2 for s in n))
             count = np.zeros(val.shape, dtype=np.int64)
@@ -468,6 +474,8 @@ def visc_extrapolate3d(gres, num_iter, vx, vy, vz, sphi):
 
 
 def _visc_row(axis, gres, scale, mu, V, sphi, vol, rhs):
+    if min(_face_shape(gres, axis)) < 3:
+        return (slice(0, 0),) * 3, np.zeros((0, 0, 0))      # no interior face in this row
     dg, comp, I = _row_views(gres, axis)
     row = VISC_ROWS[axis]
     vs = {k: dg(vol, o) for k, o in _VOL_OFF.items()}

@@ -1,0 +1,111 @@
+"""Edge cases of the HIP path: degenerate grids (no interior cell), ragged sizes, the
+largest single-GPU size of BASELINE (512^3 stencil), misuse that must fail loudly."""
+import numpy as np
+import pytest
+import torch
+
+from mfs import _lib, scenes
+from mfs.pcg import PcgEngine
+from oracle import mfs_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+@pytest.mark.parametrize("gres", [(1, 1, 1), (2, 2, 2), (2, 5, 3), (3, 3, 3), (3, 2, 7), (5, 3, 4)])
+def test_degenerate_grids_match_oracle(gres):
+    """grids with zero or one interior cell: every kernel is a no-op or a single cell, never a fault"""
+    import solver.CGSolverBuffer as B
+    import solver.PressureCGSolver3D as P
+    sc = scenes.pressure_scene_3d(gres, seed=3, vel_dtype=np.float64, solid_velocity=True)
+    ref = O.PressureCGSolver3D(gres, sc["bound_size"])
+    rv = [sc["vx"].copy(), sc["vy"].copy(), sc["vz"].copy()]
+    ref.solve(*rv, sc["sphi"], sc["sv"], sc["lphi"])
+    buf = B.CGSolverBuffer(gres, device=DEV)
+    s = P.PressureCGSolver3D(buf, gres, sc["bound_size"])
+    v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
+    s.solve(*v, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]))
+    assert s.iterations == ref.iterations
+    h0 = max(ref.history[0], 1e-300)
+    np.testing.assert_allclose(s.history, np.array(ref.history), rtol=1e-9, atol=1e-20 * h0)   # the tail is round-off zero
+    for a, b in zip(v, rv):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=1e-10, atol=1e-12)
+
+
+def test_degenerate_viscosity_grids():
+    import solver.ViscosityCGSolver3D as V
+    for gres in ((2, 2, 2), (3, 3, 3), (4, 3, 5)):
+        sc = scenes.viscosity_scene_3d(gres, seed=1, vel_dtype=np.float64)
+        ref = O.ViscosityCGSolver3D(gres, sc["bound_size"])
+        rv = [sc["vx"].copy(), sc["vy"].copy(), sc["vz"].copy()]
+        ref.solve(sc["dt"], sc["mu"], sc["rho"], *rv, sc["sphi"], sc["sv"], sc["lphi"], sc["lvol"])
+        s = V.ViscosityCGSolver3D(gres, sc["bound_size"], device=DEV)
+        v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
+        s.solve(sc["dt"], sc["mu"], sc["rho"], *v, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]), T(sc["lvol"]))
+        assert s.iterations == ref.iterations
+        for a, b in zip(v, rv):
+            np.testing.assert_allclose(a.cpu().numpy(), b, rtol=1e-9, atol=1e-12)
+
+
+def test_512_cubed_stencil_properties():
+    """BASELINE's largest per-GPU stencil (config 4 is 512^3 over 8 GPUs; here the whole 512^3 on one):
+    symmetry, plane-range decomposition == whole, variant 0 (direct) == variant 2 (LDS march), bit for bit."""
+    import solver.SolidFraction3D as S
+    N = 512
+    gres = (N, N, N)
+    dt = torch.float32
+    sc = scenes.pressure_scene_3d(gres, seed=6, device=DEV, x_range=None)
+    wx = torch.zeros((N + 1, N, N), dtype=dt, device=DEV)
+    wy = torch.zeros((N, N + 1, N), dtype=dt, device=DEV)
+    wz = torch.zeros((N, N, N + 1), dtype=dt, device=DEV)
+    S.compute_solid_frac(gres, sc["sphi"], wx, wy, wz)
+    eng = PcgEngine(gres, dt, DEV)
+    eng.setup(sc["lphi"], wx, wy, wz)
+    del sc
+    torch.cuda.empty_cache()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    u = torch.randn(gres, generator=gen, device=DEV, dtype=dt)
+    v = torch.randn(gres, generator=gen, device=DEV, dtype=dt)
+    for t in (u, v):
+        t[0] = 0; t[-1] = 0; t[:, 0] = 0; t[:, -1] = 0; t[:, :, 0] = 0; t[:, :, -1] = 0
+    Au, Av = torch.zeros(gres, dtype=dt, device=DEV), torch.zeros(gres, dtype=dt, device=DEV)
+    eng.apply(u, Au)
+    eng.apply(v, Av)
+    uAv, vAu, uAu = (u.double() * Av.double()).sum().item(), (v.double() * Au.double()).sum().item(), (u.double() * Au.double()).sum().item()
+    assert abs(uAv - vAu) <= 2e-6 * max(abs(uAv), abs(uAu)) and uAu > 0
+    A2 = torch.zeros(gres, dtype=dt, device=DEV)
+    eng.apply(u, A2, 1, 200); eng.apply(u, A2, 200, 201); eng.apply(u, A2, 201, N - 1)
+    assert torch.equal(A2, Au)
+    eng.tune(0, 0, 2, 0)
+    A3 = torch.zeros(gres, dtype=dt, device=DEV)
+    eng.apply(u, A3)
+    assert torch.equal(A3, Au)
+
+
+def test_misuse_fails_loudly():
+    import solver.CGSolverBuffer as B
+    import solver.PressureCGSolver3D as P
+    gres = (8, 8, 8)
+    buf = B.CGSolverBuffer(gres, device=DEV)
+    s = P.PressureCGSolver3D(buf, gres, 1.0)
+    sc = scenes.pressure_scene_3d(gres, seed=0)
+    good = dict(vx=T(sc["vx"]), vy=T(sc["vy"]), vz=T(sc["vz"]), sphi=T(sc["sphi"]), sv=T(sc["sv"]), lphi=T(sc["lphi"]))
+    with pytest.raises(ValueError, match="shape"):
+        s.solve(good["vy"], good["vy"], good["vz"], good["sphi"], good["sv"], good["lphi"])
+    with pytest.raises(TypeError, match="GPU"):
+        s.solve(good["vx"].cpu(), good["vy"], good["vz"], good["sphi"], good["sv"], good["lphi"])
+    with pytest.raises(ValueError, match="contiguous"):
+        s.solve(good["vx"].transpose(1, 2), good["vy"], good["vz"], good["sphi"], good["sv"], good["lphi"])
+    with pytest.raises(TypeError, match="dtype"):
+        s.solve(good["vx"].to(torch.float16), good["vy"], good["vz"], good["sphi"], good["sv"], good["lphi"])
+    eng = PcgEngine(gres, torch.float64, DEV)
+    with pytest.raises(_lib.MfsError, match="setup"):
+        eng.apply(torch.zeros(gres, dtype=torch.float64, device=DEV), torch.zeros(gres, dtype=torch.float64, device=DEV))
+    with pytest.raises(_lib.MfsError, match="in place"):
+        eng.setup(good["lphi"], s.wx, s.wy, s.wz)
+        z = torch.zeros(gres, dtype=torch.float64, device=DEV)
+        eng.apply(z, z)
