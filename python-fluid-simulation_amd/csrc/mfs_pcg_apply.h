@@ -43,19 +43,24 @@ __device__ __forceinline__ void stencil_vec(T* __restrict__ out_ptr, vec_t<T, VE
                                             vec_t<T, VEC> cyp, vec_t<T, VEC> cym, vec_t<T, VEC> czm, double zl,
                                             double zr, double czr, bool first, bool last, bool active, double& acc) {
   vec_t<T, VEC> o;
+#ifdef MFS_APPLY_NATIVE_MATH   // experiment: arithmetic in the storage type
+  typedef T C;
+#else
+  typedef double C;
+#endif
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    const double zm = j == 0 ? zl : (double)vc[j == 0 ? 0 : j - 1];
-    const double zp = j == VEC - 1 ? zr : (double)vc[j == VEC - 1 ? j : j + 1];
-    const double czp = j == VEC - 1 ? czr : (double)czm[j == VEC - 1 ? j : j + 1];
-    double val = 0.0;
-    val -= (double)cxp[j] * (double)vxp[j];
-    val -= (double)cxm[j] * (double)vxm[j];
-    val -= (double)cyp[j] * (double)vyp[j];
-    val -= (double)cym[j] * (double)vym[j];
+    const C zm = j == 0 ? (C)zl : (C)vc[j == 0 ? 0 : j - 1];
+    const C zp = j == VEC - 1 ? (C)zr : (C)vc[j == VEC - 1 ? j : j + 1];
+    const C czp = j == VEC - 1 ? (C)czr : (C)czm[j == VEC - 1 ? j : j + 1];
+    C val = 0;
+    val -= (C)cxp[j] * (C)vxp[j];
+    val -= (C)cxm[j] * (C)vxm[j];
+    val -= (C)cyp[j] * (C)vyp[j];
+    val -= (C)cym[j] * (C)vym[j];
     val -= czp * zp;
-    val -= (double)czm[j] * zm;
-    val += (double)dg[j] * (double)vc[j];
+    val -= (C)czm[j] * zm;
+    val += (C)dg[j] * (C)vc[j];
     o[j] = (T)val;
     const bool bnd = (first && j == 0) || (last && j == VEC - 1);
     if (active && !bnd) acc += (double)vc[j] * (double)o[j];

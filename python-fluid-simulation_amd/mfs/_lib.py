@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfs_hip.so")
+LIB_PATH = os.environ.get("MFS_LIB") or os.path.join(_HERE, "libmfs_hip.so")   # MFS_LIB: A/B builds of the same ABI
 
 MFS_F32, MFS_F64 = 0, 1
 MFS_OK, MFS_NOT_CONVERGED = 0, 1
