@@ -157,6 +157,10 @@ void* mfs_pcg3d_scalars(mfs_pcg3d* h);
  * nontemporal > 0 marks the once-read coefficient streams, 0 never, < 0 = auto
  * (on when the six arrays of one apply exceed the Infinity Cache).                */
 int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int nontemporal);
+/* compressed coefficient access (default on): the per-iteration kernel reads the four
+ * coefficient arrays only for z-vectors that are neither all-zero rows nor regular
+ * interior rows (class byte per vector built by mfs_pcg3d_setup); results are bit-identical */
+int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
 
 /* ------------------------------------------------------------------------- */
 /* Viscosity, 3D -- stateless kernels (the reference's module-level functions) */

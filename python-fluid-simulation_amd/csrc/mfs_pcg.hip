@@ -68,6 +68,8 @@ struct mfs_pcg3d {
   char* ws;
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
+  unsigned char* cls;          // class byte per z-vector (compressed coefficient access)
+  int compress;                // 1: per-iteration kernel skips the coefficient arrays of ZERO / REGULAR vectors
   int grid_apply, cus;
   int variant, xchunk, nt, bpc, nt_auto;   // apply-kernel tuning (mfs_pcg3d_tune)
   bool vec_ok;
@@ -85,8 +87,9 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
   const int nzv = h->Nz / VEC;
   const int64_t ipp = (int64_t)(h->Ny - 2) * nzv;
   int variant = h->variant;
-  const size_t lds = 2 * ((size_t)kApplyBlock * VEC + 2 * (size_t)h->Nz) * sizeof(T);
-  if (variant == 2 && lds > 64 * 1024) variant = 1;          // absurdly long rows: skip the LDS image
+  const int ry = variant == 3 ? 2 : (variant == 4 ? 4 : 1);
+  const size_t lds = 2 * ((size_t)ry * kApplyBlock * VEC + 2 * (size_t)h->Nz) * sizeof(T);
+  if (variant >= 2 && lds > 64 * 1024) variant = 1;          // absurdly long rows: skip the LDS image
   const int xchunk = std::max(0, h->xchunk);   // 0 = no cap on the length of one march
   ApplyArgs a{h->Nx, h->Ny, h->Nz, xb, xe, xchunk, xb2, xe2};
   const int np = (xe - xb) + (xe2 - xb2);
@@ -97,7 +100,7 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
                        partial, done);
     *grid_out = grid;
   } else {
-    const int64_t tiles = (ipp + kApplyBlock - 1) / kApplyBlock;
+    const int64_t tiles = (ipp + (int64_t)ry * kApplyBlock - 1) / ((int64_t)ry * kApplyBlock);
     const int64_t total = tiles * np;                 // (tile, plane) pairs, cut into `grid` equal segments
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kMaxPartials, h->cus * h->bpc), total));
     // Nontemporal loads for the once-read coefficient streams pay off only when the
@@ -106,21 +109,36 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
     // bit 0: diag, cz   bit 1: cx   bit 2: cy   -- the once-per-iteration coefficient streams.
     // < 0 = auto: all of them when the apply's six arrays exceed the Infinity Cache.
     const int nt = h->nt < 0 ? ((6.0 * (double)h->n * sizeof(T) > 200e6) ? h->nt_auto : 0) : (h->nt & 7);
-#define MFS_MARCH(LDSF, NTV) \
-    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, v, out, \
-                       dg, cx, cy, cz, a, partial, done)
-    if (variant == 2) {
+#define MFS_MARCH(LDSF, NTV, CMP) \
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV, CMP>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, v, \
+                       out, dg, cx, cy, cz, h->cls, a, partial, done)
+    const bool comp = h->compress != 0 && VEC > 1;
+#define MFS_MARCH_R(NTV, CMP, RYV) \
+    hipLaunchKernelGGL((k_pcg_apply_march_r<T, VEC, NTV, CMP, RYV>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, \
+                       cx, cy, cz, h->cls, a, partial, done)
+    if (variant == 3 || variant == 4) {
+      if (variant == 3) {
+        if (comp) { if (nt) MFS_MARCH_R(7, true, 2); else MFS_MARCH_R(0, true, 2); }
+        else      { if (nt) MFS_MARCH_R(7, false, 2); else MFS_MARCH_R(0, false, 2); }
+      } else {
+        if (comp) { if (nt) MFS_MARCH_R(7, true, 4); else MFS_MARCH_R(0, true, 4); }
+        else      { if (nt) MFS_MARCH_R(7, false, 4); else MFS_MARCH_R(0, false, 4); }
+      }
+    } else if (variant == 2 && comp) {
+      if (nt) MFS_MARCH(true, 7, true); else MFS_MARCH(true, 0, true);
+    } else if (variant == 2) {
       switch (nt) {
-        case 0: MFS_MARCH(true, 0); break;
-        case 1: MFS_MARCH(true, 1); break;
-        case 3: MFS_MARCH(true, 3); break;
-        case 5: MFS_MARCH(true, 5); break;
-        default: MFS_MARCH(true, 7); break;
+        case 0: MFS_MARCH(true, 0, false); break;
+        case 1: MFS_MARCH(true, 1, false); break;
+        case 3: MFS_MARCH(true, 3, false); break;
+        case 5: MFS_MARCH(true, 5, false); break;
+        default: MFS_MARCH(true, 7, false); break;
       }
     } else {
-      if (nt) MFS_MARCH(false, 1); else MFS_MARCH(false, 0);
+      if (nt) MFS_MARCH(false, 1, false); else MFS_MARCH(false, 0, false);
     }
 #undef MFS_MARCH
+#undef MFS_MARCH_R
     *grid_out = grid;
   }
   MFS_LAUNCH_CHECK();
@@ -155,7 +173,7 @@ extern "C" {
 size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   const int64_t n = gres[0] * gres[1] * gres[2];
-  return core_ws_bytes() + 4 * coef_stride(n, dtype_size(dt)) + 4096;
+  return core_ws_bytes() + 4 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096);
 }
 
 int64_t mfs_pcg3d_history_capacity(void) { return kHistCap; }
@@ -176,6 +194,8 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   p = (char*)align_up((uintptr_t)p, 4096);
   const size_t cs = coef_stride(h->n, h->c.elt);
   h->diag = p; h->cx = p + cs; h->cy = p + 2 * cs; h->cz = p + 3 * cs;
+  h->cls = (unsigned char*)(p + 4 * cs);
+  h->compress = env_int("MFS_APPLY_COMPRESS", 1);
   const int vec = dt == MFS_F32 ? 4 : 2;
   h->vec_ok = (h->Nz % vec) == 0 && h->Nz >= 2 * vec;
   h->cus = h->c.cus;
@@ -216,6 +236,20 @@ int mfs_pcg3d_setup(mfs_pcg3d* h, const void* lphi, int lphi_dt, const void* wx,
                        lphi, lphi_dt, wx, wy, wz, w_dt, (double*)h->diag, (double*)h->cx, (double*)h->cy,
                        (double*)h->cz);
   MFS_LAUNCH_CHECK();
+  if (h->vec_ok) {   // class byte per z-vector for the compressed coefficient access
+    if (h->dt == MFS_F32) {
+      const int64_t nvec = h->n / 4;
+      hipLaunchKernelGGL((k_pcg_classify<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)h->diag, (const float*)h->cx, (const float*)h->cy, (const float*)h->cz, h->Nx,
+                         h->Ny, h->Nz, h->cls);
+    } else {
+      const int64_t nvec = h->n / 2;
+      hipLaunchKernelGGL((k_pcg_classify<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const double*)h->diag, (const double*)h->cx, (const double*)h->cy, (const double*)h->cz,
+                         h->Nx, h->Ny, h->Nz, h->cls);
+    }
+    MFS_LAUNCH_CHECK();
+  }
   h->is_setup = true;
   return MFS_OK;
 }
@@ -239,7 +273,7 @@ void* mfs_pcg3d_scalars(mfs_pcg3d* h) { return h ? h->c.scal : nullptr; }
 
 int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int nontemporal) {
   MFS_REQUIRE(h, "null handle");
-  MFS_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0 (direct), 1 (march) or 2 (march + LDS)");
+  MFS_REQUIRE(variant >= 0 && variant <= 4, "variant: 0 direct, 1 march, 2 march+LDS, 3 / 4 march+LDS with 2 / 4 vectors per thread");
   MFS_REQUIRE(xchunk >= 0 && blocks_per_cu >= 1, "xchunk must be >= 0 (0 = no cap), blocks_per_cu >= 1");
   h->variant = variant; h->xchunk = xchunk; h->bpc = blocks_per_cu;
   h->nt = nontemporal < 0 ? -1 : (nontemporal & 7);
@@ -248,6 +282,12 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
     h->c.rev_xr = (nontemporal >> 4) & 1;   // experiment bits: sweep direction of the vector phases
     h->c.rev_d = (nontemporal >> 5) & 1;
   }
+  return MFS_OK;
+}
+
+int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->compress = on != 0;
   return MFS_OK;
 }
 

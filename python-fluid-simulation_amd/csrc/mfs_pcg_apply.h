@@ -124,6 +124,84 @@ k_pcg_apply_direct(const T* __restrict__ v, T* __restrict__ out, const T* __rest
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------ coefficient access ---
+// The seven coefficients of the cells of one z-vector of one plane, as fetched
+// ("raw") plus the vector's class.  Dense mode: raw is the truth.  Compressed
+// mode (COMP): a byte per z-vector (k_pcg_classify) says whether every computed
+// cell of the vector is a ZERO row (all seven coefficients 0: non-fluid), a REGULAR
+// row (six face weights 1, diag 6: fluid cell away from solids and the free
+// surface) or anything else (MIXED).  Only MIXED vectors read the four coefficient
+// arrays; the others are reconstructed from the class, bit-identically.  In a
+// fluid solve almost every vector is ZERO or REGULAR, so the kernel's HBM traffic
+// drops from 6 to ~2.5 scalars per cell.  Lanes of non-MIXED vectors aim their
+// (unconditional, branch-free) loads at one dummy line so they cost no bandwidth.
+enum : unsigned char { kClsZero = 0, kClsRegular = 1, kClsMixed = 2 };
+
+template <typename T, int VEC>
+struct CoefVec {
+  vec_t<T, VEC> dg, cxm, cxp, cym, cyp, czm;
+  unsigned char cls;
+};
+
+template <typename T, int VEC, bool COMP, int NT>
+__device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag, const T* __restrict__ cx,
+                                                     const T* __restrict__ cy, const T* __restrict__ cz,
+                                                     int64_t b, int64_t sx, int Nz, unsigned char cls) {
+  CoefVec<T, VEC> c;
+  c.cls = cls;
+  const bool real = !COMP || cls == kClsMixed;
+  // dummy target: the first vector of `diag` (always mapped, 16-byte aligned)
+  const int64_t o0 = real ? b : 0, o1 = real ? b + sx : 0, o2 = real ? b + Nz : 0;
+  c.dg = (NT & 1) ? vload_nt<T, VEC>(diag + o0) : vload<T, VEC>(diag + o0);
+  if (COMP) c.cxm = vload<T, VEC>((real ? cx : diag) + o0);   // dense mode carries cx[x] over from the previous step
+  else c.cxm = c.dg;
+  c.cxp = (NT & 2) ? vload_nt<T, VEC>((real ? cx : diag) + o1) : vload<T, VEC>((real ? cx : diag) + o1);
+  c.cym = (NT & 4) ? vload_nt<T, VEC>((real ? cy : diag) + o0) : vload<T, VEC>((real ? cy : diag) + o0);
+  c.cyp = (NT & 4) ? vload_nt<T, VEC>((real ? cy : diag) + o2) : vload<T, VEC>((real ? cy : diag) + o2);
+  c.czm = (NT & 1) ? vload_nt<T, VEC>((real ? cz : diag) + o0) : vload<T, VEC>((real ? cz : diag) + o0);
+  return c;
+}
+
+// effective coefficients at use time (after the loads have landed)
+template <typename T, int VEC, bool COMP>
+__device__ __forceinline__ void coef_resolve(CoefVec<T, VEC>& c) {
+  if (!COMP) return;
+  if (c.cls != kClsMixed) {
+    const T f = c.cls == kClsRegular ? (T)1 : (T)0, d = c.cls == kClsRegular ? (T)6 : (T)0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { c.dg[j] = d; c.cxm[j] = f; c.cxp[j] = f; c.cym[j] = f; c.cyp[j] = f; c.czm[j] = f; }
+  }
+}
+
+// class of every z-vector from the dense coefficient arrays (once per solve)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_pcg_classify(const T* __restrict__ diag, const T* __restrict__ cx, const T* __restrict__ cy,
+               const T* __restrict__ cz, int Nx, int Ny, int Nz, unsigned char* __restrict__ cls) {
+  const int nzv = Nz / VEC;
+  const int64_t nvec = (int64_t)Nx * Ny * nzv;
+  const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (iv >= nvec) return;
+  const int zv = (int)(iv % nzv), y = (int)((iv / nzv) % Ny), x = (int)(iv / ((int64_t)nzv * Ny));
+  const int64_t sx = (int64_t)Ny * Nz, b = iv * VEC;
+  bool all_zero = true, all_reg = true;
+  if (x > 0 && x < Nx - 1 && y > 0 && y < Ny - 1) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int z = zv * VEC + j;
+      if (z == 0 || z == Nz - 1) continue;                  // boundary cells are never computed: don't care
+      const int64_t c = b + j;
+      const T k[7] = {diag[c], cx[c], cx[c + sx], cy[c], cy[c + Nz], cz[c], cz[c + 1]};
+      bool z0 = true, r1 = k[0] == (T)6;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { z0 = z0 && k[q] == (T)0; if (q) r1 = r1 && k[q] == (T)1; }
+      all_zero = all_zero && z0;
+      all_reg = all_reg && r1;
+    }
+  }
+  cls[iv] = all_zero ? kClsZero : (all_reg ? kClsRegular : kClsMixed);
+}
+
 // ------------------------------------------------------------- variant 1/2 --
 // x-marching.  LDS=true stages the current plane tile (+ one row of halo each
 // side) in LDS; LDS=false reads the y neighbours straight from global/L1.
@@ -133,11 +211,12 @@ k_pcg_apply_direct(const T* __restrict__ v, T* __restrict__ out, const T* __rest
 // memory segment [m0, m0 + 256*VEC) of each plane, its y-1 / y+1 neighbours are
 // the same segment shifted by -/+ Nz, and the LDS image is simply
 //   [ Nz halo | 256*VEC tile | Nz halo ]   elements of T.
-template <typename T, int VEC, bool LDS, int NT>
+template <typename T, int VEC, bool LDS, int NT, bool COMP>
 __global__ void __launch_bounds__(kApplyBlock)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
-                  const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz, ApplyArgs a,
-                  double* __restrict__ partial, const double* __restrict__ done_flag) {
+                  const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
+                  const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
+                  const double* __restrict__ done_flag) {
   if (done_flag && *done_flag != 0.0) return;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* const smem = reinterpret_cast<T*>(smem_raw);
@@ -187,12 +266,14 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
 
     int64_t base = (int64_t)x0 * sx + m;
     vec_t<T, VEC> vm = vload<T, VEC>(v + base - sx), vc = vload<T, VEC>(v + base), vp = vload<T, VEC>(v + base + sx);
-    vec_t<T, VEC> cxm = vload<T, VEC>(cx + base);
-    vec_t<T, VEC> cxp = (NT & 2) ? vload_nt<T, VEC>(cx + base + sx) : vload<T, VEC>(cx + base + sx);
-    vec_t<T, VEC> dg = (NT & 1) ? vload_nt<T, VEC>(diag + base) : vload<T, VEC>(diag + base);
-    vec_t<T, VEC> cym = (NT & 4) ? vload_nt<T, VEC>(cy + base) : vload<T, VEC>(cy + base);
-    vec_t<T, VEC> cyp = (NT & 4) ? vload_nt<T, VEC>(cy + base + Nz) : vload<T, VEC>(cy + base + Nz);
-    vec_t<T, VEC> czm = (NT & 1) ? vload_nt<T, VEC>(cz + base) : vload<T, VEC>(cz + base);
+    // classes of this vector in planes x0 and x0+1 (compressed mode), then plane x0's coefficients
+    unsigned char cls_n = kClsMixed, cls_c = kClsMixed;
+    if (COMP) {
+      cls_c = cls[base / VEC];
+      cls_n = cls[(base + (x0 + 1 < x1 ? sx : 0)) / VEC];
+    }
+    CoefVec<T, VEC> cc = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, base, sx, Nz, cls_c);
+    if (!COMP) cc.cxm = vload<T, VEC>(cx + base);
 
     if (LDS) {
       // stage plane x0 (tile + halos) into buffer 0
@@ -224,11 +305,11 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const int64_t nn = more ? nb : base;                  // plane x+1 (or x again on the last step)
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
       const vec_t<T, VEC> vpp = vload<T, VEC>(v + n2);
-      const vec_t<T, VEC> cxpp = (NT & 2) ? vload_nt<T, VEC>(cx + n2) : vload<T, VEC>(cx + n2);
-      const vec_t<T, VEC> dg_n = (NT & 1) ? vload_nt<T, VEC>(diag + nn) : vload<T, VEC>(diag + nn);
-      const vec_t<T, VEC> cym_n = (NT & 4) ? vload_nt<T, VEC>(cy + nn) : vload<T, VEC>(cy + nn);
-      const vec_t<T, VEC> cyp_n = (NT & 4) ? vload_nt<T, VEC>(cy + nn + Nz) : vload<T, VEC>(cy + nn + Nz);
-      const vec_t<T, VEC> czm_n = (NT & 1) ? vload_nt<T, VEC>(cz + nn) : vload<T, VEC>(cz + nn);
+      // plane x+1's coefficients (class known since the previous step); class of plane x+2
+      CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls);
+      if (!COMP) cn.cxm = cc.cxp;                           // cx[x+1] was this step's upper-face weight
+      unsigned char cls_nn = kClsMixed;
+      if (COMP) cls_nn = cls[n2 / VEC];
       vec_t<T, VEC> hlo_n = {}, hhi_n = {};                           // halos of plane x+2, published one step later
       if (LDS && hofs < Nz) {
         const int64_t hp = (int64_t)(more ? x + 2 : x + 1) * sx + m0;
@@ -251,10 +332,11 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
         zl = (double)((lane == 0 && !first) ? v[base - 1] : l);
         zr = (double)((lane == 63 && !last) ? v[base + VEC] : r);
       }
-      const T czs = __shfl_down(czm[0], 1, 64);
+      coef_resolve<T, VEC, COMP>(cc);
+      const T czs = __shfl_down(cc.czm[0], 1, 64);
       const double czr = (double)((lane == 63 && !last) ? cz[base + VEC] : czs);
-      stencil_vec<T, VEC>(out + base, vc, vp, vm, vyp, vym, dg, cxp, cxm, cyp, cym, czm, zl, zr, czr, first, last,
-                          active, acc);
+      stencil_vec<T, VEC>(out + base, vc, vp, vm, vyp, vym, cc.dg, cc.cxp, cc.cxm, cc.cyp, cc.cym, cc.czm, zl, zr, czr,
+                          first, last, active, acc);
       // ---- rotate; publish plane x+1 to the other LDS buffer
       if (more) {
         if (LDS) {
@@ -270,12 +352,169 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        vm = vc; vc = vp; vp = vpp; cxm = cxp; cxp = cxpp; dg = dg_n; cym = cym_n; cyp = cyp_n; czm = czm_n;
+        vm = vc; vc = vp; vp = vpp; cc = cn; cls_n = cls_nn;
         hlo = hlo_n; hhi = hhi_n;
         base = nb;
       }
     }
     if (LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // next work unit reuses buffer 0
+  }
+  const double tot = block_sum<kApplyBlock>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------- variant 3 ----
+// The LDS march with RY z-vectors per thread: the tile is RY*256 consecutive
+// vectors (thread t owns vectors t, t+256, ...), so a workgroup moves RY times the
+// bytes per plane step and per barrier, and the two halo rows are amortised over a
+// tile RY times as tall.  The march is latency-paced (one dependent memory round
+// trip per plane), so fatter steps are what converts spare bandwidth into speed.
+template <typename T, int VEC, int NT, bool COMP, int RY>
+__global__ void __launch_bounds__(kApplyBlock)
+k_pcg_apply_march_r(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
+                    const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
+                    const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
+                    const double* __restrict__ done_flag) {
+  if (done_flag && *done_flag != 0.0) return;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* const smem = reinterpret_cast<T*>(smem_raw);
+  constexpr int TILEV = RY * kApplyBlock;                   // z-vectors per tile
+  const int Nz = a.Nz;
+  const int nzv = Nz / VEC;
+  const int ipp = (a.Ny - 2) * nzv;
+  const int tiles = (ipp + TILEV - 1) / TILEV;
+  const int n1 = a.xe - a.xb;
+  const int np = n1 + (a.xe2 - a.xb2);
+  const int64_t total = (int64_t)tiles * np;                // (tile, plane) pairs, cut into gridDim equal segments
+  const int G = gridDim.x;
+  const int nch = min(G, kXcds);
+  const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
+  const int per = G / nch, extra = G - per * nch;
+  const int seg = xcd * per + min(xcd, extra) + slot;
+  const int64_t s0 = total * seg / G, s1 = total * (seg + 1) / G;
+  const int64_t sx = (int64_t)a.Ny * Nz;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tile_elems = TILEV * VEC;
+  const int buf_elems = tile_elems + 2 * Nz;
+  const int hofs = tid * VEC;                               // halo slot owned by this thread (if < Nz)
+  double acc = 0.0;
+
+  for (int64_t i = s0; i < s1;) {
+    const int tile = (int)(i / np);
+    const int pl = (int)(i - (int64_t)tile * np);
+    const int x0 = pl < n1 ? a.xb + pl : a.xb2 + (pl - n1);
+    int len = (int)min((int64_t)((pl < n1 ? a.xe : a.xe2) - x0), s1 - i);
+    if (a.xchunk > 0) len = min(len, a.xchunk);
+    const int x1 = x0 + len;
+    i += len;
+    const int64_t m0 = (int64_t)Nz + (int64_t)tile * tile_elems;
+    const int tile_len = min(tile_elems, ipp * VEC - tile * tile_elems);
+
+    bool active[RY], first[RY], last[RY];
+    int64_t base[RY];
+    vec_t<T, VEC> vm[RY], vc[RY], vp[RY];
+    CoefVec<T, VEC> cc[RY];
+    unsigned char cls_n[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      const int item_raw = tile * TILEV + r * kApplyBlock + tid;
+      active[r] = item_raw < ipp;
+      const int item = active[r] ? item_raw : ipp - 1;
+      const int yy = item / nzv, zv = item - yy * nzv;
+      first[r] = zv == 0;
+      last[r] = zv == nzv - 1;
+      base[r] = (int64_t)x0 * sx + (int64_t)(yy + 1) * Nz + (int64_t)zv * VEC;
+      vm[r] = vload<T, VEC>(v + base[r] - sx);
+      vc[r] = vload<T, VEC>(v + base[r]);
+      vp[r] = vload<T, VEC>(v + base[r] + sx);
+      unsigned char c0 = kClsMixed;
+      cls_n[r] = kClsMixed;
+      if (COMP) {
+        c0 = cls[base[r] / VEC];
+        cls_n[r] = cls[(base[r] + (x0 + 1 < x1 ? sx : 0)) / VEC];
+      }
+      cc[r] = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, base[r], sx, Nz, c0);
+      if (!COMP) cc[r].cxm = vload<T, VEC>(cx + base[r]);
+    }
+    {  // stage plane x0 (tile + halos) into buffer 0
+      T* b0 = smem;
+#pragma unroll
+      for (int r = 0; r < RY; ++r)
+        if (active[r]) vstore<T, VEC>(b0 + Nz + (r * kApplyBlock + tid) * VEC, vc[r]);
+      for (int h = hofs; h < Nz; h += kApplyBlock * VEC) {
+        vstore<T, VEC>(b0 + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 - Nz + h));
+        vstore<T, VEC>(b0 + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 + tile_len + h));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    vec_t<T, VEC> hlo = {}, hhi = {};                       // halo vectors of plane x0+1
+    if (hofs < Nz) {
+      const int64_t hp = (int64_t)min(x0 + 1, x1) * sx + m0;
+      hlo = vload<T, VEC>(v + hp - Nz + hofs);
+      hhi = vload<T, VEC>(v + hp + tile_len + hofs);
+    }
+
+    for (int x = x0; x < x1; ++x) {
+      const bool more = x + 1 < x1;
+      const int cur = (x - x0) & 1;
+      // ---- prefetch (unconditional, clamped on the last step): plane x+2 of v, plane x+1's coefficients
+      vec_t<T, VEC> vpp[RY];
+      CoefVec<T, VEC> cn[RY];
+      unsigned char cls_nn[RY];
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        const int64_t nb = base[r] + sx;
+        const int64_t nn = more ? nb : base[r], n2 = more ? nb + sx : nb;
+        vpp[r] = vload<T, VEC>(v + n2);
+        cn[r] = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n[r] : cc[r].cls);
+        if (!COMP) cn[r].cxm = cc[r].cxp;
+        cls_nn[r] = kClsMixed;
+        if (COMP) cls_nn[r] = cls[n2 / VEC];
+      }
+      vec_t<T, VEC> hlo_n = {}, hhi_n = {};
+      if (hofs < Nz) {
+        const int64_t hp = (int64_t)(more ? x + 2 : x + 1) * sx + m0;
+        hlo_n = vload<T, VEC>(v + hp - Nz + hofs);
+        hhi_n = vload<T, VEC>(v + hp + tile_len + hofs);
+      }
+      // ---- plane x: in-plane neighbours from LDS, stencil, store
+      const T* bc = smem + cur * buf_elems;
+#pragma unroll
+      for (int r = 0; r < RY; ++r) {
+        const int lo = (r * kApplyBlock + tid) * VEC;        // this vector inside the tile
+        const vec_t<T, VEC> vym = vload<T, VEC>(bc + lo);
+        const vec_t<T, VEC> vyp = vload<T, VEC>(bc + 2 * Nz + lo);
+        const double zl = (double)bc[Nz + lo - 1], zr = (double)bc[Nz + lo + VEC];
+        coef_resolve<T, VEC, COMP>(cc[r]);
+        const T czs = __shfl_down(cc[r].czm[0], 1, 64);
+        const double czr = (double)((lane == 63 && !last[r]) ? cz[base[r] + VEC] : czs);
+        stencil_vec<T, VEC>(out + base[r], vc[r], vp[r], vm[r], vyp, vym, cc[r].dg, cc[r].cxp, cc[r].cxm, cc[r].cyp,
+                            cc[r].cym, cc[r].czm, zl, zr, czr, first[r], last[r], active[r], acc);
+      }
+      // ---- rotate; publish plane x+1 to the other LDS buffer
+      if (more) {
+        T* bn = smem + (cur ^ 1) * buf_elems;
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+          if (active[r]) vstore<T, VEC>(bn + Nz + (r * kApplyBlock + tid) * VEC, vp[r]);
+        if (hofs < Nz) {
+          vstore<T, VEC>(bn + hofs, hlo);
+          vstore<T, VEC>(bn + Nz + tile_len + hofs, hhi);
+        }
+        for (int h = hofs + kApplyBlock * VEC; h < Nz; h += kApplyBlock * VEC) {   // rows longer than 256 vectors
+          vstore<T, VEC>(bn + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 - Nz + h));
+          vstore<T, VEC>(bn + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 + tile_len + h));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+          vm[r] = vc[r]; vc[r] = vp[r]; vp[r] = vpp[r]; cc[r] = cn[r]; cls_n[r] = cls_nn[r];
+          base[r] += sx;
+        }
+        hlo = hlo_n; hhi = hhi_n;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // next work unit reuses buffer 0
   }
   const double tot = block_sum<kApplyBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;

@@ -46,6 +46,9 @@ class PcgEngine:
         _lib.check(self.lib.mfs_pcg3d_tune(self.h, int(variant), int(xchunk), int(blocks_per_cu), int(nontemporal)),
                    "mfs_pcg3d_tune")
 
+    def set_compress(self, on):
+        _lib.check(self.lib.mfs_pcg3d_set_compress(self.h, int(bool(on))), "mfs_pcg3d_set_compress")
+
     # -- once per solve ------------------------------------------------------
     def setup(self, lphi, wx, wy, wz):
         g = self.gres

@@ -117,6 +117,12 @@ def test_engine_apply_matches_reference_operator(mods, name, dt):
     ref = np.full(gres, 7.0)
     O.pressure_apply3d(gres, v.cpu().numpy().astype(np.float64), ref, g["wx"], g["wy"], g["wz"], g["lphi"])
     close(out, ref, 1e-12 if dt == torch.float64 else 2e-7, "engine apply")
+    # compressed coefficient access (default) == dense access, bit for bit
+    eng.set_compress(False)
+    outd = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    eng.apply(v, outd)
+    assert torch.equal(out, outd)
+    eng.set_compress(True)
     # plane-range form: two halves == whole
     out2 = torch.full(gres, 7.0, dtype=dt, device=DEV)
     mid = gres[0] // 2
@@ -278,7 +284,9 @@ def test_full_size_properties(mods, dt, N):
     eng.apply(z, Az)
     assert (Az[1:-1, 1:-1, 1:-1] == 0).all()
     Au2 = torch.full(gres, 7.0, dtype=dt, device=DEV)
+    eng.set_compress(False)          # dense coefficient access: identical bits
     eng.apply(u, Au2)
+    eng.set_compress(True)
     Au2[0] = 0; Au2[-1] = 0; Au2[:, 0] = 0; Au2[:, -1] = 0; Au2[:, :, 0] = 0; Au2[:, :, -1] = 0
     assert torch.equal(Au, Au2)
 

@@ -19,9 +19,18 @@ b, x, d, r, q = (torch.zeros(gres, dtype=dt, device=dev) for _ in range(5))
 P.initialize_solver(sc["cell_size"], gres, sc["vx"], sc["vy"], sc["vz"], sc["sphi"], sc["sv"], sc["lphi"], b, wx, wy, wz)
 eng = PcgEngine(gres, dt, dev); eng.setup(sc["lphi"], wx, wy, wz); eng.bind(b, x, d, r, q)
 del sc; torch.cuda.empty_cache()
-cfgs = [int(a) for a in sys.argv[4:]] or [0, 1, 3, 5, 7, 8, 9, 15]
-for nt in cfgs:
-    eng.tune(2, 0, 2, nt)
+# config = "variant,bpc,nt,compress" strings
+cfgs = sys.argv[4:] or ["2,2,15,1", "3,2,15,1", "3,1,15,1", "4,1,15,1", "3,2,15,0", "4,1,15,0"]
+ref = None
+for c in cfgs:
+    var, bpc, nt, comp = (int(t) for t in c.split(","))
+    eng.set_compress(comp)
+    eng.tune(var, 0, bpc, nt)
     eng.begin(0.0); eng.iterate(10); torch.cuda.synchronize()
     t0 = time.perf_counter(); eng.iterate(iters); torch.cuda.synchronize(); t = (time.perf_counter() - t0) / iters
-    print(f"nt bits {nt:2d} (coef diag/cz={nt&1} cx={(nt>>1)&1} cy={(nt>>2)&1} x={(nt>>3)&1}): {t*1e6:8.2f} us/iter  {N**3/t/1e9:7.2f} Gcell/s", flush=True)
+    a_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    o = torch.zeros_like(q); eng.apply(d, o); a_.record()
+    for _ in range(20): eng.apply(d, o)
+    e_.record(); torch.cuda.synchronize()
+    if ref is None: ref = o.clone()
+    print(f"variant {var} bpc {bpc} nt {nt:2d} compress {comp}: {t*1e6:8.2f} us/iter  {N**3/t/1e9:7.2f} Gcell/s   apply b2b {a_.elapsed_time(e_)/20*1e3:7.2f} us  equal={torch.equal(o, ref)}", flush=True)
