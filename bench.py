@@ -171,7 +171,12 @@ def main():
         Nx, Ny, Nz = lgres
         alg_bytes = (6 * Nx * Ny * Nz + 3 * Ny * Nz) * esz     # 6N^3+3N^2 scalars per apply
         reps = max(20, min(args.steps, 200))
-        # (a) inside real CG iterations: events bracket each apply launch
+        # inside real CG iterations: HIP events (on the stream the kernel is launched on) bracket each
+        # apply launch; an empty event pair is timed the same way for reference
+        cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for s_ev, e_ev in cal:
+            s_ev.record()
+            e_ev.record()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for s_ev, e_ev in evs:
             s_ev.record()
@@ -179,7 +184,12 @@ def main():
             e_ev.record()
             eng.phase_reduce(0); eng.phase_update_xr(); eng.phase_reduce(1); eng.phase_update_d()
         torch.cuda.synchronize()
-        ms_cg = sum(s.elapsed_time(e) for s, e in evs) / reps
+        ev_over = sorted(s.elapsed_time(e) for s, e in cal)[len(cal) // 2]
+        ms_raw = sum(s.elapsed_time(e) for s, e in evs) / reps
+        # NOT subtracted: an empty pair (~9 us) over-states what two records cost around a running kernel
+        # (rocprofv3 gives 63.2 us for the kernel whose bracketed time is 66.5 us); the bracketed time is the
+        # conservative figure and is what `achieved` uses.
+        ms_cg = ms_raw
         ms_b2b = None
         if args.b2b:   # back-to-back applies (Infinity-Cache-warm; NOT what the CG loop sees)
             s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -204,7 +214,8 @@ def main():
                 traffic = None
         rf = {"bound": "hbm", "kernel": "k_pcg_apply_march", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-              "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5)}
+              "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5),
+              "kernel_ms_raw_events": round(ms_raw, 5), "event_pair_overhead_ms": round(ev_over, 5)}
         if ms_b2b:
             rf["kernel_ms_back_to_back"] = round(ms_b2b, 5)
             rf["achieved_back_to_back"] = round(alg_bytes / (ms_b2b * 1e-3) / 1e9, 1)
