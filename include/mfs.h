@@ -246,6 +246,21 @@ int mfs_pcg2d_poll(mfs_pcg2d* h, mfs_stream stream, int64_t* iters_host, int* do
                    double* delta_host, double* alpha_host, double* beta_host);
 int64_t mfs_pcg2d_history(mfs_pcg2d* h, double* out_host, int64_t cap, mfs_stream stream);
 
+/* ------------------------------------------------------------------------- */
+/* Notebook grid kernels that bracket the two solves    */
+/* ------------------------------------------------------------------------- */
+/* replaces `extrapolate(gres, num_iter, vx, vy, vz, mx, my, mz)` -- 3D_viscous_fluid_sim.ipynb code cell 7
+ * (call site ipynb:4652): validity = grid mass > 0.  Workspace as for mfs_visc_extrapolate3d.          */
+int mfs_grid_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
+                           const void* mx, const void* my, const void* mz, int m_dt,
+                           void* workspace, size_t workspace_bytes, mfs_stream stream);
+/* replaces the three kernels of `apply_boundary_condition(g, solid, dx)` -- code cell 5 (call site
+ * ipynb:4655): writes the free-slip corrections dv_x, dv_y, dv_z (the caller adds them to the velocities) */
+int mfs_grid_boundary_condition3d(const int64_t gres[3], const void* gvx, const void* gvy, const void* gvz, int v_dt,
+                                  const void* gmx, const void* gmy, const void* gmz, int m_dt,
+                                  const void* sphi, int sphi_dt, const void* sv, int sv_dt, double dx,
+                                  void* dvx, void* dvy, void* dvz, int dv_dt, mfs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -562,3 +562,95 @@ class ViscosityCGSolver3D:
             (self.r_x, self.r_y, self.r_z), (self.q_x, self.q_y, self.q_z), tol,
             self.max_iter if max_iter is None else max_iter, self.history, raise_on_fail)
         visc_writeback3d(self.gres, vx, vy, vz, self.x_x, self.x_y, self.x_z, sphi, sv)
+
+
+# =============================================================================
+# the notebook's grid kernels that bracket the two solves
+# (3D_viscous_fluid_sim.ipynb code cells 5 and 7; "ipynb cN:L" = line L of code cell N)
+# =============================================================================
+def nb_extrapolate(gres, num_iter, vx, vy, vz, mx, my, mz):
+    """ipynb c7:1-64 (`extrapolate`, called at ipynb:4652 with num_iter=2): the same Jacobi
+    sweep as the viscosity solver's, with validity = grid mass > 0 instead of sphi >= 0."""
+    valids = [np.asarray(mx) > 0, np.asarray(my) > 0, np.asarray(mz) > 0]
+    for _ in range(num_iter):
+        for v, valid in zip((vx, vy, vz), valids):
+            n = v.shape
+            if min(n) < 3:
+                continue
+            I = (slice(1, n[0] - 1), slice(1, n[1] - 1), slice(1, n[2] - 1))
+            val = np.zeros(tuple(s - 2 for s in n))
+            count = np.zeros(val.shape, dtype=np.int64)
+            for off in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+                sl = tuple(slice(1 + o, s - 1 + o) for o, s in zip(off, n))
+                m = valid[sl]
+                val = val + np.where(m, v[sl].astype(F64), 0.0)
+                count = count + m
+            upd = (~valid[I]) & (count > 0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                v[I] = np.where(upd, val / count, v[I].astype(F64)).astype(v.dtype)
+            nv = valid.copy()
+            nv[I] = valid[I] | upd
+            valid[...] = nv
+
+
+def nb_boundary_condition(gres, gv, gm, sphi, sv, dx, dv):
+    """ipynb c5:1-146 (`boundary_condition_{x,y,z}`): dv = -(component of the solid-relative
+    velocity's inward normal part) * (1 - sphi/dx) on interior faces closer than dx to a solid;
+    0 elsewhere (array-boundary faces included).  gv, gm, dv are (x,y,z) triples of face arrays.
+
+    The mass-weighted averages multiply velocity by mass in the INPUT dtype (fp32 in the
+    notebook, numba/numpy scalar promotion) before accumulating in fp64.  `min(0, s)` is
+    `s if s < 0 else 0` (NaN -> 0, e.g. where the averaged mass is 0).
+    Reference quirk (not reproduced): the kernels store `dv[x,y,z] = 0` BEFORE comparing x,y,z
+    with the array shape, so threads of the rounded-up launch grid store out of bounds -- on
+    the GPU some of those stores race with interior faces of the next plane.  The intended
+    (race-free) result is restated here; tests/golden/make_goldens_notebook.py drops those stores.
+    """
+    sphi = np.asarray(sphi, F64)
+    sv = np.asarray(sv, F64)
+    D0 = ((0, 1, 1), (1, 0, 1), (1, 1, 0))
+    # per component: the two other components and their 4 (ix, iy) sample offsets, as written in c5
+    #   x: vy,gmy at (x-ix, y+iy, z) ; vz,gmz at (x-ix, y, z+iy)
+    #   y: vx,gmx at (x+iz, y-iy, z) ; vz,gmz at (x, y-iy, z+iz)
+    #   z: vx,gmx at (x+ix, y, z-iz) ; vy,gmy at (x, y+ix, z-iz)
+    taps = {
+        0: ((1, [(-ix, iy, 0) for ix in range(2) for iy in range(2)]), (2, [(-ix, 0, iy) for ix in range(2) for iy in range(2)])),
+        1: ((0, [(iz, -iy, 0) for iy in range(2) for iz in range(2)]), (2, [(0, -iy, iz) for iy in range(2) for iz in range(2)])),
+        2: ((0, [(ix, 0, -iz) for iz in range(2) for ix in range(2)]), (1, [(0, ix, -iz) for iz in range(2) for ix in range(2)])),
+    }
+    for a in range(3):
+        n = gv[a].shape
+        dv[a][...] = 0
+        if min(n) < 3:
+            continue
+        cnt = tuple(s - 2 for s in n)
+        I = tuple(slice(1, 1 + c) for c in cnt)
+
+        def dg(G, off, comp=None):
+            sl = tuple(slice(2 + D0[a][k] + off[k], 2 + D0[a][k] + off[k] + 2 * cnt[k], 2) for k in range(3))
+            return G[sl] if comp is None else G[sl + (comp,)]
+
+        def sh(A, off):
+            return np.asarray(A)[tuple(slice(1 + off[k], 1 + off[k] + cnt[k]) for k in range(3))]
+
+        ndist = dg(sphi, (0, 0, 0)) / dx
+        vel = [None, None, None]
+        vel[a] = sh(gv[a], (0, 0, 0)).astype(F64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for comp, offs in taps[a]:
+                msum = np.zeros(cnt)
+                vsum = np.zeros(cnt)
+                for off in offs:
+                    m_ = sh(gm[comp], off)
+                    v_ = sh(gv[comp], off)
+                    msum = msum + m_.astype(F64)
+                    vsum = vsum + (v_ * m_).astype(F64)       # product in the arrays' own dtype
+                vel[comp] = vsum / msum
+            rel = [vel[c] - dg(sv, (0, 0, 0), c) for c in range(3)]
+            e = np.eye(3, dtype=int)
+            sn = [dg(sphi, tuple(e[c])) - dg(sphi, tuple(-e[c])) for c in range(3)]
+            sn_inv = 1.0 / (sn[0] ** 2 + sn[1] ** 2 + sn[2] ** 2)
+            s = sn[0] * rel[0] + sn[1] * rel[1] + sn[2] * rel[2]
+            proj = np.where(s < 0, s, 0.0) * sn[a] * sn_inv
+            out = -proj * (1.0 - ndist)
+        dv[a][I] = np.where(ndist >= 1, 0.0, out).astype(dv[a].dtype)

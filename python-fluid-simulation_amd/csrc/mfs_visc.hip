@@ -162,6 +162,67 @@ k_visc_writeback(G3 g, W3 v, int vdt, V3 o, int odt, const void* sphi, int sdt) 
   }
 }
 
+// ------------------------------------------ notebook grid kernels (8(f) rank 1) --
+// validity = grid mass > 0   (notebook `extrapolate`, 3D_viscous_fluid_sim.ipynb code cell 7)
+__global__ void __launch_bounds__(256) k_grid_valid_mass(int64_t n, const void* m, int mdt, unsigned char* valid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) valid[i] = ldx(m, mdt, i) > 0 ? 1 : 0;
+}
+
+// boundary_condition_{x,y,z} (notebook code cell 5).  dv = 0 on array-boundary faces and on faces at
+// least dx away from the solid; else minus the AXIS component of the inward-normal part of the
+// solid-relative velocity, faded by (1 - sphi/dx).  The velocity*mass products are formed in the
+// arrays' own dtype (fp32 in the notebook) and accumulated in fp64, as numba types them.
+// (The reference stores dv = 0 before its bounds check, i.e. out of bounds for the rounded-up
+// part of its launch grid; only in-range faces are written here.)
+template <int AXIS>
+__global__ void __launch_bounds__(256)
+k_grid_boundary_condition(G3 g, V3 gv, int vdt, V3 gm, int mdt, const void* sphi, int sdt, const void* sv, int svdt,
+                          double dx, void* dv, int dvdt) {
+  const int s0 = g.sh(AXIS, 0), s1 = g.sh(AXIS, 1), s2 = g.sh(AXIS, 2);
+  const int64_t n = (int64_t)s0 * s1 * s2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int z = (int)(i % s2), y = (int)((i / s2) % s1), x = (int)(i / ((int64_t)s2 * s1));
+  if (x == 0 || x >= s0 - 1 || y == 0 || y >= s1 - 1 || z == 0 || z >= s2 - 1) { stx(dv, dvdt, i, 0.0); return; }
+  const int Dx = 2 * x + kD0[AXIS][0], Dy = 2 * y + kD0[AXIS][1], Dz = 2 * z + kD0[AXIS][2];
+  const double ndist = ldx(sphi, sdt, g.dg(Dx, Dy, Dz)) / dx;
+  if (ndist >= 1) { stx(dv, dvdt, i, 0.0); return; }
+  double vel[3] = {0.0, 0.0, 0.0};
+  vel[AXIS] = ldx(gv.p[AXIS], vdt, i);
+  const bool f32prod = vdt == MFS_F32 && mdt == MFS_F32;
+  // the two other components: 4 samples each, offsets as written in the notebook's loops
+  constexpr int CA = AXIS == 0 ? 1 : 0, CB = AXIS == 2 ? 1 : 2;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const int comp = w == 0 ? CA : CB;
+    double msum = 0.0, vsum = 0.0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int ox, oy, oz;
+        if (AXIS == 0) { ox = -p; oy = w == 0 ? q : 0; oz = w == 0 ? 0 : q; }          // x: (x-ix, y+iy, z) / (x-ix, y, z+iy)
+        else if (AXIS == 1) { ox = w == 0 ? q : 0; oy = -p; oz = w == 0 ? 0 : q; }     // y: (x+iz, y-iy, z) / (x, y-iy, z+iz)
+        else { ox = w == 0 ? q : 0; oy = w == 0 ? 0 : q; oz = -p; }                    // z: (x+ix, y, z-iz) / (x, y+ix, z-iz)
+        const int64_t f = g.fidx(comp, x + ox, y + oy, z + oz);
+        const double mm = ldx(gm.p[comp], mdt, f), vv = ldx(gv.p[comp], vdt, f);
+        msum += mm;
+        vsum += f32prod ? (double)((float)vv * (float)mm) : vv * mm;
+      }
+    vel[comp] = vsum / msum;
+  }
+  const int64_t sc = 3 * g.dg(Dx, Dy, Dz);
+  const double rx = vel[0] - ldx(sv, svdt, sc + 0), ry = vel[1] - ldx(sv, svdt, sc + 1), rz = vel[2] - ldx(sv, svdt, sc + 2);
+  const double snx = ldx(sphi, sdt, g.dg(Dx + 1, Dy, Dz)) - ldx(sphi, sdt, g.dg(Dx - 1, Dy, Dz));
+  const double sny = ldx(sphi, sdt, g.dg(Dx, Dy + 1, Dz)) - ldx(sphi, sdt, g.dg(Dx, Dy - 1, Dz));
+  const double snz = ldx(sphi, sdt, g.dg(Dx, Dy, Dz + 1)) - ldx(sphi, sdt, g.dg(Dx, Dy, Dz - 1));
+  const double sn_inv = 1.0 / (snx * snx + sny * sny + snz * snz);
+  const double s = snx * rx + sny * ry + snz * rz;
+  const double proj = (s < 0 ? s : 0.0) * (AXIS == 0 ? snx : (AXIS == 1 ? sny : snz)) * sn_inv;   // min(0, s): NaN -> 0
+  stx(dv, dvdt, i, -proj * (1.0 - ndist));
+}
+
 // ------------------------------------------------------------ compact form ---
 // parity class code p = (i&1)<<2 | (j&1)<<1 | (k&1) of a doubled-grid node;
 // class array dims: odd axis -> N, even axis -> N+1; compact index = node >> 1.
@@ -431,16 +492,17 @@ size_t mfs_visc_extrapolate3d_workspace_bytes(const int64_t gres[3], int v_dt) {
   return tot;
 }
 
-int mfs_visc_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
-                           const void* sphi, int sphi_dt, void* workspace, size_t workspace_bytes,
-                           mfs_stream stream) {
+// shared by the viscosity solver's extrapolate (validity = sphi >= 0 at the face) and the notebook's
+// (validity = grid mass > 0): num_iter Jacobi sweeps, ping-pong buffers in `workspace`
+static int extrapolate_impl(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
+                            const void* sphi, int sphi_dt, const void* const mass[3], int m_dt, void* workspace,
+                            size_t workspace_bytes, hipStream_t st) {
   if (int e = check_gres(gres)) return e;
-  MFS_REQUIRE(vx && vy && vz && sphi && workspace, "null array");
-  MFS_REQUIRE(dtype_ok(v_dt) && dtype_ok(sphi_dt), "dtype");
+  MFS_REQUIRE(vx && vy && vz && workspace, "null array");
+  MFS_REQUIRE(dtype_ok(v_dt), "dtype");
   MFS_REQUIRE(num_iter >= 0, "num_iter");
   MFS_REQUIRE(workspace_bytes >= mfs_visc_extrapolate3d_workspace_bytes(gres, v_dt), "workspace too small");
   MFS_REQUIRE(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
   G3 g = make_g(gres);
   void* v[3] = {vx, vy, vz};
   char* p = (char*)workspace;
@@ -450,9 +512,13 @@ int mfs_visc_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* 
     unsigned char* va = (unsigned char*)p; p += align_up((size_t)n, 256);
     unsigned char* vb = (unsigned char*)p; p += align_up((size_t)n, 256);
     const int grid = cdiv(n, 256);
-    if (c == 0) hipLaunchKernelGGL((k_visc_valid<0>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
-    if (c == 1) hipLaunchKernelGGL((k_visc_valid<1>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
-    if (c == 2) hipLaunchKernelGGL((k_visc_valid<2>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
+    if (mass) {
+      hipLaunchKernelGGL(k_grid_valid_mass, dim3(grid), dim3(256), 0, st, n, mass[c], m_dt, va);
+    } else {
+      if (c == 0) hipLaunchKernelGGL((k_visc_valid<0>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
+      if (c == 1) hipLaunchKernelGGL((k_visc_valid<1>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
+      if (c == 2) hipLaunchKernelGGL((k_visc_valid<2>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, va);
+    }
     void *cur = v[c], *oth = tmp;
     unsigned char *mcur = va, *moth = vb;
     for (int it = 0; it < num_iter; ++it) {
@@ -464,6 +530,45 @@ int mfs_visc_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* 
     MFS_LAUNCH_CHECK();
     if (cur != v[c]) MFS_HIP_TRY(hipMemcpyAsync(v[c], cur, (size_t)n * dtype_size(v_dt), hipMemcpyDeviceToDevice, st));
   }
+  return MFS_OK;
+}
+
+int mfs_visc_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
+                           const void* sphi, int sphi_dt, void* workspace, size_t workspace_bytes,
+                           mfs_stream stream) {
+  MFS_REQUIRE(sphi, "null array");
+  MFS_REQUIRE(dtype_ok(sphi_dt), "dtype");
+  return extrapolate_impl(gres, num_iter, vx, vy, vz, v_dt, sphi, sphi_dt, nullptr, 0, workspace, workspace_bytes,
+                          (hipStream_t)stream);
+}
+
+int mfs_grid_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
+                           const void* mx, const void* my, const void* mz, int m_dt, void* workspace,
+                           size_t workspace_bytes, mfs_stream stream) {
+  MFS_REQUIRE(mx && my && mz, "null array");
+  MFS_REQUIRE(dtype_ok(m_dt), "dtype");
+  const void* const mass[3] = {mx, my, mz};
+  return extrapolate_impl(gres, num_iter, vx, vy, vz, v_dt, nullptr, 0, mass, m_dt, workspace, workspace_bytes,
+                          (hipStream_t)stream);
+}
+
+int mfs_grid_boundary_condition3d(const int64_t gres[3], const void* gvx, const void* gvy, const void* gvz, int v_dt,
+                                  const void* gmx, const void* gmy, const void* gmz, int m_dt, const void* sphi,
+                                  int sphi_dt, const void* sv, int sv_dt, double dx, void* dvx, void* dvy, void* dvz,
+                                  int dv_dt, mfs_stream stream) {
+  if (int e = check_gres(gres)) return e;
+  MFS_REQUIRE(gvx && gvy && gvz && gmx && gmy && gmz && sphi && sv && dvx && dvy && dvz, "null array");
+  MFS_REQUIRE(dtype_ok(v_dt) && dtype_ok(m_dt) && dtype_ok(sphi_dt) && dtype_ok(sv_dt) && dtype_ok(dv_dt), "dtype");
+  G3 g = make_g(gres);
+  V3 gv{{gvx, gvy, gvz}}, gm{{gmx, gmy, gmz}};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((k_grid_boundary_condition<0>), dim3(cdiv(g.nface(0), 256)), dim3(256), 0, st, g, gv, v_dt, gm, m_dt,
+                     sphi, sphi_dt, sv, sv_dt, dx, dvx, dv_dt);
+  hipLaunchKernelGGL((k_grid_boundary_condition<1>), dim3(cdiv(g.nface(1), 256)), dim3(256), 0, st, g, gv, v_dt, gm, m_dt,
+                     sphi, sphi_dt, sv, sv_dt, dx, dvy, dv_dt);
+  hipLaunchKernelGGL((k_grid_boundary_condition<2>), dim3(cdiv(g.nface(2), 256)), dim3(256), 0, st, g, gv, v_dt, gm, m_dt,
+                     sphi, sphi_dt, sv, sv_dt, dx, dvz, dv_dt);
+  MFS_LAUNCH_CHECK();
   return MFS_OK;
 }
 

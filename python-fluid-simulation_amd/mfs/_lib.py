@@ -86,6 +86,8 @@ SIGNATURES = {
     "mfs_vcg3d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
     "mfs_vcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
     "mfs_vcg3d_history": (_i64, [_p, _pd, _i64, _p]),
+    "mfs_grid_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
+    "mfs_grid_boundary_condition3d": (_i, [_pi64, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _d, _p, _p, _p, _i, _p]),
     "mfs_pressure_rhs2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "mfs_pressure_apply2d": (_i, [_pi64, _p, _p, _i, _p, _p, _i, _p, _i, _p]),
     "mfs_pressure_update2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p]),

@@ -28,9 +28,11 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("MFS_REFERENCE", "/root/reference")
 
 sys.dont_write_bytecode = True          # the reference mount is read-only
+# order matters: the plumbing first, then the REFERENCE's `solver` package (it must shadow this repo's
+# own drop-in package of the same name), then this repo's package for `mfs.scenes` only
+sys.path.insert(0, os.path.join(REPO, "python-fluid-simulation_amd"))
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(HERE, "refshim"))
-sys.path.insert(0, os.path.join(REPO, "python-fluid-simulation_amd"))
 
 import numpy as np  # noqa: E402
 import cupy as cp   # noqa: E402  (tests/golden/refshim/cupy.py)

@@ -19,6 +19,44 @@ int32 = _np.int32
 bool_ = _np.bool_
 
 
+class _f32(_np.float32):
+    """float32 scalar read out of an array, with numba's typing of mixed expressions: a Python
+    float literal is a float64 (`0.0 + f32 -> f64`), whereas numpy >= 2 (NEP 50) treats Python
+    scalars as weak (`0.0 + f32 -> f32`).  f32 (op) f32 stays f32, as in numba.  Container-only
+    plumbing: no solver arithmetic."""
+
+    def _wide(self, other):
+        return isinstance(other, (float, int)) and not isinstance(other, (_np.generic, bool))
+
+    def __add__(self, o):
+        return _np.float64(self) + o if self._wide(o) else _wrap_scalar(_np.float32.__add__(self, o))
+
+    def __radd__(self, o):
+        return o + _np.float64(self) if self._wide(o) else _wrap_scalar(_np.float32.__radd__(self, o))
+
+    def __sub__(self, o):
+        return _np.float64(self) - o if self._wide(o) else _wrap_scalar(_np.float32.__sub__(self, o))
+
+    def __rsub__(self, o):
+        return o - _np.float64(self) if self._wide(o) else _wrap_scalar(_np.float32.__rsub__(self, o))
+
+    def __mul__(self, o):
+        return _np.float64(self) * o if self._wide(o) else _wrap_scalar(_np.float32.__mul__(self, o))
+
+    def __rmul__(self, o):
+        return o * _np.float64(self) if self._wide(o) else _wrap_scalar(_np.float32.__rmul__(self, o))
+
+    def __truediv__(self, o):
+        return _np.float64(self) / o if self._wide(o) else _wrap_scalar(_np.float32.__truediv__(self, o))
+
+    def __rtruediv__(self, o):
+        return o / _np.float64(self) if self._wide(o) else _wrap_scalar(_np.float32.__rtruediv__(self, o))
+
+
+def _wrap_scalar(v):
+    return _f32(v) if type(v) is _np.float32 else v
+
+
 class ndarray(_np.ndarray):
     """numpy array with cupy's device->host accessor."""
 
@@ -27,6 +65,10 @@ class ndarray(_np.ndarray):
 
     def item(self, *a):
         return _np.asarray(self).item(*a)
+
+    def __getitem__(self, idx):
+        v = _np.ndarray.__getitem__(self, idx)
+        return _f32(v) if type(v) is _np.float32 else v
 
 
 def _wrap(a):

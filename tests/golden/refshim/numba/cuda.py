@@ -15,6 +15,10 @@ import itertools
 import numpy as _np
 
 _tid = None  # thread index of the body currently being executed
+# Some notebook kernels store to `dv[x,y,z]` BEFORE their bounds check, for every thread of a launch
+# grid that is rounded up to multiples of 8 -- an out-of-bounds store on the GPU (numba does not check),
+# which never lands inside the logical array.  With ignore_oob set, such a thread is a no-op here.
+ignore_oob = False
 
 
 class _Kernel:
@@ -34,7 +38,13 @@ class _Kernel:
             fn = self.fn
             for idx in itertools.product(*(range(e) for e in extent)):
                 _tid = idx
-                fn(*args)
+                if ignore_oob:
+                    try:
+                        fn(*args)
+                    except IndexError:
+                        pass
+                else:
+                    fn(*args)
             _tid = None
 
         return launch
