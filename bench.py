@@ -169,7 +169,10 @@ def main():
     rf = None
     if rank == 0:
         Nx, Ny, Nz = lgres
-        alg_bytes = (6 * Nx * Ny * Nz + 3 * Ny * Nz) * esz     # 6N^3+3N^2 scalars per apply
+        # the dominant kernel of the timed loop is the stencil apply WITH the direction update folded in:
+        # SURVEY.md 8(d)'s stencil figure (6N^3+3N^2 scalars: v,4 coefficient arrays in, out) plus the update's
+        # r in and d_new out, with d_old taking the place of v = 8N^3+3N^2 scalars per launch
+        alg_bytes = (8 * Nx * Ny * Nz + 3 * Ny * Nz) * esz
         reps = max(20, min(args.steps, 200))
         # inside real CG iterations: HIP events (on the stream the kernel is launched on) bracket each
         # apply launch; an empty event pair is timed the same way for reference
@@ -180,9 +183,9 @@ def main():
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for s_ev, e_ev in evs:
             s_ev.record()
-            eng.phase_apply(1, Nx - 1, True)
+            eng.native_apply()          # the stencil launch of one native iteration (fused direction update)
             e_ev.record()
-            eng.phase_reduce(0); eng.phase_update_xr(); eng.phase_reduce(1); eng.phase_update_d()
+            eng.native_finish()
         torch.cuda.synchronize()
         ev_over = sorted(s.elapsed_time(e) for s, e in cal)[len(cal) // 2]
         ms_raw = sum(s.elapsed_time(e) for s, e in evs) / reps
@@ -212,7 +215,7 @@ def main():
                     traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        rf = {"bound": "hbm", "kernel": "k_pcg_apply_march", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        rf = {"bound": "hbm", "kernel": "k_pcg_apply_march<..., FUSE=true> (stencil apply + d = r + beta d)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
               "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5),
               "kernel_ms_raw_events": round(ms_raw, 5), "event_pair_overhead_ms": round(ev_over, 5)}

@@ -110,6 +110,10 @@ int mfs_pcg3d_bind(mfs_pcg3d* h, void* b, void* x, void* d, void* r, void* q);
 int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream);
 /* enqueue n CG iterations (lines 207-221); iterations after convergence are device-side no-ops */
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream);
+/* the two halves of ONE iteration of mfs_pcg3d_iterate (so a caller can bracket the stencil launch
+ * with events): the stencil launch, then the x/r update and the direction update / its bookkeeping */
+int mfs_pcg3d_native_apply(mfs_pcg3d* h, mfs_stream stream);
+int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream);
 /* synchronises `stream`, then reports the device-resident solver state. host call. */
 int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);
@@ -161,6 +165,9 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
  * coefficient arrays only for z-vectors that are neither all-zero rows nor regular
  * interior rows (class byte per vector built by mfs_pcg3d_setup); results are bit-identical */
 int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
+/* fused direction update (default on, native loop only): `d = r + beta d` is formed inside the next
+ * stencil launch instead of in a pass of its own; bit-identical; d ping-pongs with an engine buffer */
+int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on);
 
 /* ------------------------------------------------------------------------- */
 /* Viscosity, 3D -- stateless kernels (the reference's module-level functions) */

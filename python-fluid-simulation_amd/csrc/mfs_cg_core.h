@@ -186,6 +186,28 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
   }, rev != 0);
 }
 
+// The bookkeeping half of k_update_d on its own (one block): r.r from the partials, convergence
+// test (:218), history, iteration count, delta ring, beta (:220).  Used when the direction update
+// itself is folded into the next stencil launch (mfs_pcg_apply.h, FUSE).
+static __global__ void __launch_bounds__(kBlock)
+k_cg_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
+          const double* __restrict__ part_rr, int npart) {
+  if (scal[S_DONE] != 0.0) return;
+  const double rr = block_total_of(part_rr, npart);
+  if (threadIdx.x == 0) {
+    const double delta = scal[S_RING + par], dq = scal[S_DQ];
+    const int64_t it = (int64_t)scal[S_ITERS];
+    if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+    scal[S_ITERS] = (double)(it + 1);
+    scal[S_RING + (par ^ 1)] = rr;
+    scal[S_RR] = rr;
+    scal[S_DELTA] = delta;
+    scal[S_LASTRR] = rr;
+    scal[S_ALPHA] = delta / dq;
+    if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rr / delta;
+  }
+}
+
 // x *= 0.0 (:198) -- a multiply, not a memset, so NaN/inf survive as in the reference.
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_scale0(T* __restrict__ x, int64_t n) {
@@ -313,7 +335,7 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
 }
 
 #define MFS_XR(TT, VV, NN, MM) \
-  hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x, (const TT*)c.d, \
+  hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x, (const TT*)dsrc, \
                      (TT*)c.r, (const TT*)c.q, c.n, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), c.part_dq, \
                      fold ? c.n_part_dq : 0)
 #define MFS_XR_MODE(MM)                                                                                              \
@@ -323,8 +345,9 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
     if (!vec) MFS_XR(double, 1, false, MM); else if (ntx) MFS_XR(double, 2, true, MM); else MFS_XR(double, 2, false, MM); \
   }
 // mode 0: x and r together; 1: r only (+ r.r partials); 2: x only
-static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode = 0) {
+static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode = 0, const void* d_override = nullptr) {
   MFS_REQUIRE(c.x, "engine not bound");
+  const void* dsrc = d_override ? d_override : c.d;
   const bool vec = core_vec_ok(c);
   const int grid = core_vec_grid(c, vec);
   const bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
@@ -349,6 +372,14 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st) {
   }
   MFS_LAUNCH_CHECK();
   ++c.iter_enq;      // the d update closes an iteration
+  return MFS_OK;
+}
+
+static inline int core_book(CgCore& c, hipStream_t st) {
+  hipLaunchKernelGGL(k_cg_book, dim3(1), dim3(kBlock), 0, st, c.scal, c.hist, kHistCap, (int)(c.iter_enq & 1), c.part_rr,
+                     c.n_part_rr);
+  MFS_LAUNCH_CHECK();
+  ++c.iter_enq;      // closes an iteration (like core_update_d)
   return MFS_OK;
 }
 

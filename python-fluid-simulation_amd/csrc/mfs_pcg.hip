@@ -68,6 +68,8 @@ struct mfs_pcg3d {
   char* ws;
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
+  void* d2;                    // ping-pong partner of the bound d (fused direction update)
+  int fuse;                    // 1: native loop folds d = r + beta d into the stencil launch
   unsigned char* cls;          // class byte per z-vector (compressed coefficient access)
   int compress;                // 1: per-iteration kernel skips the coefficient arrays of ZERO / REGULAR vectors
   int grid_apply, cus;
@@ -80,9 +82,11 @@ struct mfs_pcg3d {
 // streams of one tile do not all start on the same HBM channel/bank phase.
 static size_t coef_stride(int64_t n, size_t elt) { return align_up((size_t)n * elt, 4096) + 4096 * 3 + 256; }
 
+struct FuseArgs { const void* r; const void* d_old; void* d_new; };
+
 template <typename T, int VEC>
 static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int xb2, int xe2, double* partial,
-                          const double* done, hipStream_t st, int* grid_out) {
+                          const double* done, hipStream_t st, int* grid_out, const FuseArgs* fz = nullptr) {
   const T *dg = (const T*)h->diag, *cx = (const T*)h->cx, *cy = (const T*)h->cy, *cz = (const T*)h->cz;
   const int nzv = h->Nz / VEC;
   const int64_t ipp = (int64_t)(h->Ny - 2) * nzv;
@@ -110,13 +114,21 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
     // < 0 = auto: all of them when the apply's six arrays exceed the Infinity Cache.
     const int nt = h->nt < 0 ? ((6.0 * (double)h->n * sizeof(T) > 200e6) ? h->nt_auto : 0) : (h->nt & 7);
 #define MFS_MARCH(LDSF, NTV, CMP) \
-    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV, CMP>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, v, \
-                       out, dg, cx, cy, cz, h->cls, a, partial, done)
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV, CMP, false>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, \
+                       v, out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, \
+                       (const double*)nullptr)
+#define MFS_MARCH_F(NTV, CMP) \
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, \
+                       dg, cx, cy, cz, h->cls, a, partial, done, (const T*)fz->r, (const T*)fz->d_old, (T*)fz->d_new, \
+                       h->c.scal + S_BETA)
     const bool comp = h->compress != 0 && VEC > 1;
 #define MFS_MARCH_R(NTV, CMP, RYV) \
     hipLaunchKernelGGL((k_pcg_apply_march_r<T, VEC, NTV, CMP, RYV>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, \
                        cx, cy, cz, h->cls, a, partial, done)
-    if (variant == 3 || variant == 4) {
+    if (fz) {   // direction update folded in: LDS march only (the caller checked variant == 2 and VEC > 1)
+      if (comp) { if (nt) MFS_MARCH_F(7, true); else MFS_MARCH_F(0, true); }
+      else      { if (nt) MFS_MARCH_F(7, false); else MFS_MARCH_F(0, false); }
+    } else if (variant == 3 || variant == 4) {
       if (variant == 3) {
         if (comp) { if (nt) MFS_MARCH_R(7, true, 2); else MFS_MARCH_R(0, true, 2); }
         else      { if (nt) MFS_MARCH_R(7, false, 2); else MFS_MARCH_R(0, false, 2); }
@@ -138,6 +150,7 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
       if (nt) MFS_MARCH(false, 1, false); else MFS_MARCH(false, 0, false);
     }
 #undef MFS_MARCH
+#undef MFS_MARCH_F
 #undef MFS_MARCH_R
     *grid_out = grid;
   }
@@ -147,25 +160,27 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
 
 template <typename T>
 static int launch_apply(mfs_pcg3d* h, const void* v, void* out, int xb, int xe, int xb2, int xe2, double* partial,
-                        int use_done, hipStream_t st, int* grid_out) {
+                        int use_done, hipStream_t st, int* grid_out, const FuseArgs* fz = nullptr) {
   if (xe < xb) xe = xb;
   if (xe2 < xb2) xe2 = xb2;
   if ((xe - xb) + (xe2 - xb2) <= 0) { *grid_out = 0; return MFS_OK; }
   constexpr int VEC = VecOf<T>::N;
   const bool vec = h->vec_ok && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 16 == 0);
   const double* done = use_done ? h->c.scal + S_DONE : nullptr;
-  if (vec) return launch_apply_v<T, VEC>(h, (const T*)v, (T*)out, xb, xe, xb2, xe2, partial, done, st, grid_out);
+  if (vec) return launch_apply_v<T, VEC>(h, (const T*)v, (T*)out, xb, xe, xb2, xe2, partial, done, st, grid_out, fz);
+  MFS_REQUIRE(fz == nullptr, "fused direction update needs the vector path");
   return launch_apply_v<T, 1>(h, (const T*)v, (T*)out, xb, xe, xb2, xe2, partial, done, st, grid_out);
 }
 
 static int apply_dispatch(mfs_pcg3d* h, const void* v, void* out, int64_t xb, int64_t xe, double* partial,
-                          int use_done, hipStream_t st, int* grid_out, int64_t xb2 = 0, int64_t xe2 = 0) {
+                          int use_done, hipStream_t st, int* grid_out, int64_t xb2 = 0, int64_t xe2 = 0,
+                          const FuseArgs* fz = nullptr) {
   const int lo = 1, hi = h->Nx - 1;
   auto clip = [&](int64_t v_) { return (int)std::max<int64_t>(lo, std::min<int64_t>(hi, v_)); };
   if (h->Ny < 3 || h->Nz < 3) { *grid_out = 0; return MFS_OK; }
   const int b = clip(xb), e = clip(xe), b2 = clip(xb2), e2 = xe2 > xb2 ? clip(xe2) : b2;
-  return h->dt == MFS_F32 ? launch_apply<float>(h, v, out, b, e, b2, e2, partial, use_done, st, grid_out)
-                          : launch_apply<double>(h, v, out, b, e, b2, e2, partial, use_done, st, grid_out);
+  return h->dt == MFS_F32 ? launch_apply<float>(h, v, out, b, e, b2, e2, partial, use_done, st, grid_out, fz)
+                          : launch_apply<double>(h, v, out, b, e, b2, e2, partial, use_done, st, grid_out, fz);
 }
 
 extern "C" {
@@ -173,7 +188,7 @@ extern "C" {
 size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   const int64_t n = gres[0] * gres[1] * gres[2];
-  return core_ws_bytes() + 4 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096);
+  return core_ws_bytes() + 5 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096);
 }
 
 int64_t mfs_pcg3d_history_capacity(void) { return kHistCap; }
@@ -194,7 +209,9 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   p = (char*)align_up((uintptr_t)p, 4096);
   const size_t cs = coef_stride(h->n, h->c.elt);
   h->diag = p; h->cx = p + cs; h->cy = p + 2 * cs; h->cz = p + 3 * cs;
-  h->cls = (unsigned char*)(p + 4 * cs);
+  h->d2 = p + 4 * cs;
+  h->cls = (unsigned char*)(p + 5 * cs);
+  h->fuse = env_int("MFS_FUSE_D", 1);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
   const int vec = dt == MFS_F32 ? 4 : 2;
   h->vec_ok = (h->Nz % vec) == 0 && h->Nz >= 2 * vec;
@@ -285,6 +302,12 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
   return MFS_OK;
 }
 
+int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->fuse = on != 0;
+  return MFS_OK;
+}
+
 int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
   h->compress = on != 0;
@@ -364,15 +387,62 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   return mfs_pcg3d_begin_finish(h, stream);
 }
 
-int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
+static bool native_fuse_ok(const mfs_pcg3d* h) {
+  const bool vec_in = h->vec_ok && ((uintptr_t)h->c.d % 16 == 0) && ((uintptr_t)h->c.q % 16 == 0) &&
+                      ((uintptr_t)h->c.r % 16 == 0);
+  return h->fuse != 0 && h->variant == 2 && vec_in && h->Ny >= 3 && h->Nz >= 3 && h->Nx >= 3;
+}
+
+// the stencil launch of native iteration j = iter_enq: plain for j = 0, else with d_j = r + beta d_{j-1}
+// formed on the fly into the other buffer of the pair {bound d, d2} (beta from k_cg_book of j-1)
+int mfs_pcg3d_native_apply(mfs_pcg3d* h, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
+  if (!native_fuse_ok(h)) return mfs_pcg3d_phase_apply(h, 1, h->Nx - 1, 1, stream);
+  const int64_t j = h->c.iter_enq;
+  void* d_cur = (j & 1) ? h->d2 : h->c.d;
+  void* d_prev = (j & 1) ? h->c.d : h->d2;
+  int grid = 0, e;
+  if (j == 0) {
+    if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid))) return e;
+  } else {
+    FuseArgs fz{h->c.r, d_prev, d_cur};
+    if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e;
+  }
+  h->c.n_part_dq = grid;
+  return MFS_OK;
+}
+
+// the rest of native iteration j: x/r update (d.q folded in) and the direction update or its bookkeeping
+int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  hipStream_t st = (hipStream_t)stream;
+  int e;
+  if (!native_fuse_ok(h)) {
+    if ((e = core_update_xr(h->c, true, st))) return e;
+    return core_update_d(h->c, true, st);
+  }
+  const int64_t j = h->c.iter_enq;
+  if ((e = core_update_xr(h->c, true, st, 0, (j & 1) ? h->d2 : h->c.d))) return e;
+  return core_book(h->c, st);
+}
+
+int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   for (int64_t i = 0; i < n; ++i) {   // 3 launches per iteration: the dots are folded into their consumers
     int e;
-    if ((e = mfs_pcg3d_phase_apply(h, 1, h->Nx - 1, 1, stream))) return e;
-    if ((e = core_update_xr(h->c, true, st))) return e;
-    if ((e = core_update_d(h->c, true, st))) return e;
+    if ((e = mfs_pcg3d_native_apply(h, stream))) return e;
+    if ((e = mfs_pcg3d_native_finish(h, stream))) return e;
   }
+  return MFS_OK;
+}
+
+// after a fused native loop the reference's `d` (d of the last completed iteration) may sit in the
+// engine's partner buffer: bring it home to the bound array (iteration count known from a poll)
+static int pcg_home_d(mfs_pcg3d* h, int64_t iters, hipStream_t st) {
+  if (!h->fuse || iters < 1 || !h->c.d) return MFS_OK;
+  if (((iters - 1) & 1) == 0) return MFS_OK;                  // d_{iters-1} already lives in the bound buffer
+  MFS_HIP_TRY(hipMemcpyAsync(h->c.d, h->d2, (size_t)h->n * h->c.elt, hipMemcpyDeviceToDevice, st));
   return MFS_OK;
 }
 
@@ -396,6 +466,7 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
     enq += n;
     if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
   }
+  if (int e = pcg_home_d(h, iters, (hipStream_t)stream)) return e;
   if (iters_host) *iters_host = iters;
   return done ? MFS_OK : MFS_NOT_CONVERGED;
 }

@@ -211,13 +211,37 @@ k_pcg_classify(const T* __restrict__ diag, const T* __restrict__ cx, const T* __
 // memory segment [m0, m0 + 256*VEC) of each plane, its y-1 / y+1 neighbours are
 // the same segment shifted by -/+ Nz, and the LDS image is simply
 //   [ Nz halo | 256*VEC tile | Nz halo ]   elements of T.
-template <typename T, int VEC, bool LDS, int NT, bool COMP>
+// Where the operand vector comes from.  Plain: v itself.  FUSE: the CG's direction update folded into
+// the stencil -- v = d_new = r + beta * d_old computed on the fly for every vector the march touches
+// (own vectors, halo rows, the x-1 / x+1 planes of the prologue), with exactly the arithmetic of
+// k_update_d, and written back once per own vector to the OTHER d buffer (neighbouring workgroups
+// still read d_old's halos, hence the ping-pong).  Saves the separate 3-scalar pass over r and d.
+template <typename T, int VEC, bool FUSE>
+struct VSrc {
+  const T* __restrict__ v;
+  const T* __restrict__ r;
+  const T* __restrict__ d_old;
+  double beta;
+  __device__ __forceinline__ vec_t<T, VEC> ld(int64_t off) const {
+    if (!FUSE) return vload<T, VEC>(v + off);
+    const vec_t<T, VEC> rv = vload<T, VEC>(r + off), dv = vload<T, VEC>(d_old + off);
+    vec_t<T, VEC> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = (T)((double)rv[j] + beta * (double)dv[j]);
+    return o;
+  }
+};
+
+template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE>
 __global__ void __launch_bounds__(kApplyBlock)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
                   const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
                   const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
-                  const double* __restrict__ done_flag) {
+                  const double* __restrict__ done_flag, const T* __restrict__ fr, const T* __restrict__ fd_old,
+                  T* __restrict__ fd_new, const double* __restrict__ beta_ptr) {
+  static_assert(!FUSE || LDS, "the fused direction update is implemented on the LDS march");
   if (done_flag && *done_flag != 0.0) return;
+  const VSrc<T, VEC, FUSE> src{v, fr, fd_old, FUSE ? *beta_ptr : 0.0};
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* const smem = reinterpret_cast<T*>(smem_raw);
   const int Nz = a.Nz;
@@ -265,7 +289,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     const int tile_len = min(tile_elems, ipp * VEC - tile * tile_elems);  // elements really in this tile
 
     int64_t base = (int64_t)x0 * sx + m;
-    vec_t<T, VEC> vm = vload<T, VEC>(v + base - sx), vc = vload<T, VEC>(v + base), vp = vload<T, VEC>(v + base + sx);
+    vec_t<T, VEC> vm = src.ld(base - sx), vc = src.ld(base), vp = src.ld(base + sx);
     // classes of this vector in planes x0 and x0+1 (compressed mode), then plane x0's coefficients
     unsigned char cls_n = kClsMixed, cls_c = kClsMixed;
     if (COMP) {
@@ -280,8 +304,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       T* b0 = smem;
       if (active) vstore<T, VEC>(b0 + Nz + tid * VEC, vc);   // inactive lanes sit past tile_len = in the halo
       for (int h = tid * VEC; h < Nz; h += kApplyBlock * VEC) {
-        vstore<T, VEC>(b0 + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 - Nz + h));
-        vstore<T, VEC>(b0 + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 + tile_len + h));
+        vstore<T, VEC>(b0 + h, src.ld((int64_t)x0 * sx + m0 - Nz + h));
+        vstore<T, VEC>(b0 + Nz + tile_len + h, src.ld((int64_t)x0 * sx + m0 + tile_len + h));
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -290,8 +314,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     vec_t<T, VEC> hlo = {}, hhi = {};
     if (LDS && hofs < Nz) {
       const int64_t hp = (int64_t)min(x0 + 1, x1) * sx + m0;
-      hlo = vload<T, VEC>(v + hp - Nz + hofs);
-      hhi = vload<T, VEC>(v + hp + tile_len + hofs);
+      hlo = src.ld(hp - Nz + hofs);
+      hhi = src.ld(hp + tile_len + hofs);
     }
 
     for (int x = x0; x < x1; ++x) {
@@ -304,7 +328,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       // waits for them where they are consumed (the rotation below), not here.
       const int64_t nn = more ? nb : base;                  // plane x+1 (or x again on the last step)
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
-      const vec_t<T, VEC> vpp = vload<T, VEC>(v + n2);
+      const vec_t<T, VEC> vpp = src.ld(n2);
       // plane x+1's coefficients (class known since the previous step); class of plane x+2
       CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls);
       if (!COMP) cn.cxm = cc.cxp;                           // cx[x+1] was this step's upper-face weight
@@ -313,8 +337,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       vec_t<T, VEC> hlo_n = {}, hhi_n = {};                           // halos of plane x+2, published one step later
       if (LDS && hofs < Nz) {
         const int64_t hp = (int64_t)(more ? x + 2 : x + 1) * sx + m0;
-        hlo_n = vload<T, VEC>(v + hp - Nz + hofs);
-        hhi_n = vload<T, VEC>(v + hp + tile_len + hofs);
+        hlo_n = src.ld(hp - Nz + hofs);
+        hhi_n = src.ld(hp + tile_len + hofs);
       }
       // ---- in-plane neighbours of plane x
       vec_t<T, VEC> vym, vyp;
@@ -337,6 +361,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const double czr = (double)((lane == 63 && !last) ? cz[base + VEC] : czs);
       stencil_vec<T, VEC>(out + base, vc, vp, vm, vyp, vym, cc.dg, cc.cxp, cc.cxm, cc.cyp, cc.cym, cc.czm, zl, zr, czr,
                           first, last, active, acc);
+      if (FUSE && active) vstore<T, VEC>(fd_new + base, vc);   // d_new of this vector (its z-boundary cells are 0 + beta*0)
       // ---- rotate; publish plane x+1 to the other LDS buffer
       if (more) {
         if (LDS) {
@@ -347,8 +372,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
             vstore<T, VEC>(bn + Nz + tile_len + hofs, hhi);
           }
           for (int h = hofs + kApplyBlock * VEC; h < Nz; h += kApplyBlock * VEC) {   // rows longer than one tile
-            vstore<T, VEC>(bn + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 - Nz + h));
-            vstore<T, VEC>(bn + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 + tile_len + h));
+            vstore<T, VEC>(bn + h, src.ld((int64_t)(x + 1) * sx + m0 - Nz + h));
+            vstore<T, VEC>(bn + Nz + tile_len + h, src.ld((int64_t)(x + 1) * sx + m0 + tile_len + h));
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mfs_pcg3d_bind": (_i, [_p, _p, _p, _p, _p, _p]),
     "mfs_pcg3d_begin": (_i, [_p, _d, _p]),
     "mfs_pcg3d_iterate": (_i, [_p, _i64, _p]),
+    "mfs_pcg3d_native_apply": (_i, [_p, _p]),
+    "mfs_pcg3d_native_finish": (_i, [_p, _p]),
     "mfs_pcg3d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
     "mfs_pcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
     "mfs_pcg3d_history": (_i64, [_p, _pd, _i64, _p]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "mfs_pcg3d_scalars": (_p, [_p]),
     "mfs_pcg3d_tune": (_i, [_p, _i, _i, _i, _i]),
     "mfs_pcg3d_set_compress": (_i, [_p, _i]),
+    "mfs_pcg3d_set_fuse": (_i, [_p, _i]),
     "mfs_visc_extrapolate3d_workspace_bytes": (_sz, [_pi64, _i]),
     "mfs_visc_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _i, _p, _sz, _p]),
     "mfs_visc_rhs3d": (_i, [_pi64, _d, _d, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),

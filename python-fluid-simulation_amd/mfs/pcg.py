@@ -46,6 +46,9 @@ class PcgEngine:
         _lib.check(self.lib.mfs_pcg3d_tune(self.h, int(variant), int(xchunk), int(blocks_per_cu), int(nontemporal)),
                    "mfs_pcg3d_tune")
 
+    def set_fuse(self, on):
+        _lib.check(self.lib.mfs_pcg3d_set_fuse(self.h, int(bool(on))), "mfs_pcg3d_set_fuse")
+
     def set_compress(self, on):
         _lib.check(self.lib.mfs_pcg3d_set_compress(self.h, int(bool(on))), "mfs_pcg3d_set_compress")
 
@@ -83,6 +86,12 @@ class PcgEngine:
 
     def iterate(self, n):
         _lib.check(self.lib.mfs_pcg3d_iterate(self.h, int(n), T.stream()), "mfs_pcg3d_iterate")
+
+    def native_apply(self):
+        _lib.check(self.lib.mfs_pcg3d_native_apply(self.h, T.stream()), "mfs_pcg3d_native_apply")
+
+    def native_finish(self):
+        _lib.check(self.lib.mfs_pcg3d_native_finish(self.h, T.stream()), "mfs_pcg3d_native_finish")
 
     def poll(self):
         it, done = C.c_int64(), C.c_int()

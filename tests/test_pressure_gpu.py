@@ -309,3 +309,25 @@ def test_full_size_solve_runs_and_reduces_divergence(mods):
     h = outs[0][1]
     assert h[-1] < 1e-4 and h[-1] < 1e-6 * h[0]
     assert (h[1::2] > 0).all()          # d.Ad > 0 : operator positive on the Krylov directions
+
+
+@pytest.mark.parametrize("name", ["p3d_d_20", "p3d_a_12", "p3d_e_allfluid_12"])
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_fused_direction_update_is_bit_identical(mods, name, prec):
+    """native loop with d = r + beta d folded into the stencil launch (default) vs the 3-kernel form"""
+    B, P, S = mods
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    res = []
+    for fuse in (True, False):
+        buf = B.CGSolverBuffer(gres, precision=prec, device=DEV)
+        s = P.PressureCGSolver3D(buf, gres, g["bound_size"], check_every=5)
+        s._engine.set_fuse(fuse)
+        v = [T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])]
+        s.solve(*v, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), tol=float(g["tol"]))
+        res.append((s.iterations, s.history, s.x.clone(), buf.d.clone(), buf.r.clone(), buf.q.clone(), v))
+    a, b = res
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    for i in (2, 3, 4, 5):
+        assert torch.equal(a[i], b[i]), i          # x, d (brought home from the partner buffer), r, q
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(a[6], b[6]))
