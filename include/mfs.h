@@ -168,6 +168,8 @@ int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
 /* fused direction update (default on, native loop only): `d = r + beta d` is formed inside the next
  * stencil launch instead of in a pass of its own; bit-identical; d ping-pongs with an engine buffer */
 int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on);
+/* planes of the operand stream the LDS march keeps in flight ahead of the plane it computes (1 or 2) */
+int mfs_pcg3d_set_prefetch(mfs_pcg3d* h, int planes);
 
 /* ------------------------------------------------------------------------- */
 /* Viscosity, 3D -- stateless kernels (the reference's module-level functions) */

@@ -186,6 +186,27 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
   }, rev != 0);
 }
 
+// d = r + beta d with beta as left in the scalar block by k_cg_book: the direction update a fused
+// native loop still owes when the host stops it WITHOUT convergence (the reference updates d at the
+// end of every non-converged iteration, :220-221)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_d_axpy(T* __restrict__ d, const T* __restrict__ r, int64_t n, const double* __restrict__ scal) {
+  if (scal[S_DONE] != 0.0) return;
+  const double beta = scal[S_BETA];
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      vec_t<T, VEC> dv = vload<T, VEC>(d + i);
+      const vec_t<T, VEC> rv = vload<T, VEC>(r + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dv[j] = (T)((double)rv[j] + beta * (double)dv[j]);
+      vstore<T, VEC>(d + i, dv);
+    } else {
+      d[i] = (T)((double)r[i] + beta * (double)d[i]);
+    }
+  });
+}
+
 // The bookkeeping half of k_update_d on its own (one block): r.r from the partials, convergence
 // test (:218), history, iteration count, delta ring, beta (:220).  Used when the direction update
 // itself is folded into the next stencil launch (mfs_pcg_apply.h, FUSE).

@@ -69,6 +69,7 @@ struct mfs_pcg3d {
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
   void* d2;                    // ping-pong partner of the bound d (fused direction update)
+  int pd;                      // prefetch depth (planes) of the operand stream in the LDS march: 1 or 2
   int fuse;                    // 1: native loop folds d = r + beta d into the stencil launch
   unsigned char* cls;          // class byte per z-vector (compressed coefficient access)
   int compress;                // 1: per-iteration kernel skips the coefficient arrays of ZERO / REGULAR vectors
@@ -114,20 +115,33 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
     // < 0 = auto: all of them when the apply's six arrays exceed the Infinity Cache.
     const int nt = h->nt < 0 ? ((6.0 * (double)h->n * sizeof(T) > 200e6) ? h->nt_auto : 0) : (h->nt & 7);
 #define MFS_MARCH(LDSF, NTV, CMP) \
-    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV, CMP, false>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, \
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV, CMP, false, 1>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, \
                        v, out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, \
                        (const double*)nullptr)
-#define MFS_MARCH_F(NTV, CMP) \
-    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, \
-                       dg, cx, cy, cz, h->cls, a, partial, done, (const T*)fz->r, (const T*)fz->d_old, (T*)fz->d_new, \
-                       h->c.scal + S_BETA)
+#define MFS_MARCH_F(NTV, CMP, PDV) \
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, PDV>), dim3(grid), dim3(kApplyBlock), lds, st, v, \
+                       out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)fz->r, (const T*)fz->d_old, \
+                       (T*)fz->d_new, h->c.scal + S_BETA)
+#define MFS_MARCH_P(NTV, CMP, PDV) \
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, false, PDV>), dim3(grid), dim3(kApplyBlock), lds, st, v, \
+                       out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, \
+                       (const double*)nullptr)
     const bool comp = h->compress != 0 && VEC > 1;
 #define MFS_MARCH_R(NTV, CMP, RYV) \
     hipLaunchKernelGGL((k_pcg_apply_march_r<T, VEC, NTV, CMP, RYV>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, \
                        cx, cy, cz, h->cls, a, partial, done)
+    const int pd = h->pd >= 2 ? 2 : 1;
     if (fz) {   // direction update folded in: LDS march only (the caller checked variant == 2 and VEC > 1)
-      if (comp) { if (nt) MFS_MARCH_F(7, true); else MFS_MARCH_F(0, true); }
-      else      { if (nt) MFS_MARCH_F(7, false); else MFS_MARCH_F(0, false); }
+      if (pd == 2) {
+        if (comp) { if (nt) MFS_MARCH_F(7, true, 2); else MFS_MARCH_F(0, true, 2); }
+        else      { if (nt) MFS_MARCH_F(7, false, 2); else MFS_MARCH_F(0, false, 2); }
+      } else {
+        if (comp) { if (nt) MFS_MARCH_F(7, true, 1); else MFS_MARCH_F(0, true, 1); }
+        else      { if (nt) MFS_MARCH_F(7, false, 1); else MFS_MARCH_F(0, false, 1); }
+      }
+    } else if (variant == 2 && pd == 2) {
+      if (comp) { if (nt) MFS_MARCH_P(7, true, 2); else MFS_MARCH_P(0, true, 2); }
+      else      { if (nt) MFS_MARCH_P(7, false, 2); else MFS_MARCH_P(0, false, 2); }
     } else if (variant == 3 || variant == 4) {
       if (variant == 3) {
         if (comp) { if (nt) MFS_MARCH_R(7, true, 2); else MFS_MARCH_R(0, true, 2); }
@@ -151,6 +165,7 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
     }
 #undef MFS_MARCH
 #undef MFS_MARCH_F
+#undef MFS_MARCH_P
 #undef MFS_MARCH_R
     *grid_out = grid;
   }
@@ -212,6 +227,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->d2 = p + 4 * cs;
   h->cls = (unsigned char*)(p + 5 * cs);
   h->fuse = env_int("MFS_FUSE_D", 1);
+  h->pd = env_int("MFS_APPLY_PD", 2);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
   const int vec = dt == MFS_F32 ? 4 : 2;
   h->vec_ok = (h->Nz % vec) == 0 && h->Nz >= 2 * vec;
@@ -299,6 +315,12 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
     h->c.rev_xr = (nontemporal >> 4) & 1;   // experiment bits: sweep direction of the vector phases
     h->c.rev_d = (nontemporal >> 5) & 1;
   }
+  return MFS_OK;
+}
+
+int mfs_pcg3d_set_prefetch(mfs_pcg3d* h, int planes) {
+  MFS_REQUIRE(h && (planes == 1 || planes == 2), "prefetch depth must be 1 or 2");
+  h->pd = planes;
   return MFS_OK;
 }
 
@@ -439,10 +461,22 @@ int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
 
 // after a fused native loop the reference's `d` (d of the last completed iteration) may sit in the
 // engine's partner buffer: bring it home to the bound array (iteration count known from a poll)
-static int pcg_home_d(mfs_pcg3d* h, int64_t iters, hipStream_t st) {
-  if (!h->fuse || iters < 1 || !h->c.d) return MFS_OK;
-  if (((iters - 1) & 1) == 0) return MFS_OK;                  // d_{iters-1} already lives in the bound buffer
-  MFS_HIP_TRY(hipMemcpyAsync(h->c.d, h->d2, (size_t)h->n * h->c.elt, hipMemcpyDeviceToDevice, st));
+static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t st) {
+  if (!native_fuse_ok(h) || iters < 1 || !h->c.d) return MFS_OK;
+  void* cur = ((iters - 1) & 1) ? h->d2 : h->c.d;             // holds d_{iters-1}
+  if (!converged) {                                           // owed: d_iters = r + beta d_{iters-1}
+    const bool vec = ((uintptr_t)cur % 16 == 0) && ((uintptr_t)h->c.r % 16 == 0);
+    const int grid = core_vec_grid(h->c, vec);
+    if (h->dt == MFS_F32) {
+      if (vec) hipLaunchKernelGGL((k_d_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)h->c.r, h->n, h->c.scal);
+      else hipLaunchKernelGGL((k_d_axpy<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)h->c.r, h->n, h->c.scal);
+    } else {
+      if (vec) hipLaunchKernelGGL((k_d_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)h->c.r, h->n, h->c.scal);
+      else hipLaunchKernelGGL((k_d_axpy<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)h->c.r, h->n, h->c.scal);
+    }
+    MFS_LAUNCH_CHECK();
+  }
+  if (cur != h->c.d) MFS_HIP_TRY(hipMemcpyAsync(h->c.d, cur, (size_t)h->n * h->c.elt, hipMemcpyDeviceToDevice, st));
   return MFS_OK;
 }
 
@@ -466,7 +500,7 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
     enq += n;
     if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
   }
-  if (int e = pcg_home_d(h, iters, (hipStream_t)stream)) return e;
+  if (int e = pcg_home_d(h, iters, done != 0, (hipStream_t)stream)) return e;
   if (iters_host) *iters_host = iters;
   return done ? MFS_OK : MFS_NOT_CONVERGED;
 }

@@ -216,23 +216,37 @@ k_pcg_classify(const T* __restrict__ diag, const T* __restrict__ cx, const T* __
 // (own vectors, halo rows, the x-1 / x+1 planes of the prologue), with exactly the arithmetic of
 // k_update_d, and written back once per own vector to the OTHER d buffer (neighbouring workgroups
 // still read d_old's halos, hence the ping-pong).  Saves the separate 3-scalar pass over r and d.
+template <typename T, int VEC>
+struct RawVec { vec_t<T, VEC> a, b; };        // as fetched: v (plain)  or  r and d_old (fused)
+
 template <typename T, int VEC, bool FUSE>
 struct VSrc {
   const T* __restrict__ v;
   const T* __restrict__ r;
   const T* __restrict__ d_old;
   double beta;
-  __device__ __forceinline__ vec_t<T, VEC> ld(int64_t off) const {
-    if (!FUSE) return vload<T, VEC>(v + off);
-    const vec_t<T, VEC> rv = vload<T, VEC>(r + off), dv = vload<T, VEC>(d_old + off);
+  // issue the loads only; nothing here depends on their data, so they stay in flight
+  __device__ __forceinline__ RawVec<T, VEC> raw(int64_t off) const {
+    RawVec<T, VEC> w;
+    if (!FUSE) { w.a = vload<T, VEC>(v + off); w.b = w.a; }
+    else { w.a = vload<T, VEC>(r + off); w.b = vload<T, VEC>(d_old + off); }
+    return w;
+  }
+  // consume: the operand vector (k_update_d's arithmetic when fused)
+  __device__ __forceinline__ vec_t<T, VEC> fin(const RawVec<T, VEC>& w) const {
+    if (!FUSE) return w.a;
     vec_t<T, VEC> o;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = (T)((double)rv[j] + beta * (double)dv[j]);
+    for (int j = 0; j < VEC; ++j) o[j] = (T)((double)w.a[j] + beta * (double)w.b[j]);
     return o;
   }
+  __device__ __forceinline__ vec_t<T, VEC> ld(int64_t off) const { return fin(raw(off)); }
 };
 
-template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE>
+// PD = prefetch depth in planes for the operand vector and its halo rows (the long-latency streams):
+// their loads for plane x+1+PD are issued at step x and consumed PD steps later, which keeps PD
+// planes of v per wave in flight -- the march is latency-paced, so bytes in flight are what set its speed.
+template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD>
 __global__ void __launch_bounds__(kApplyBlock)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
                   const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
@@ -309,13 +323,21 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    // halo vectors of plane x0+1 (published to LDS at the end of step x0)
+    // in flight from here on: the operand vector of planes x0+2 .. x0+PD and the halo rows of planes
+    // x0+1 .. x0+PD (raw; consumed PD steps after issue)
     const int hofs = tid * VEC;                             // halo slot owned by this thread (if < Nz)
-    vec_t<T, VEC> hlo = {}, hhi = {};
-    if (LDS && hofs < Nz) {
-      const int64_t hp = (int64_t)min(x0 + 1, x1) * sx + m0;
-      hlo = src.ld(hp - Nz + hofs);
-      hhi = src.ld(hp + tile_len + hofs);
+    RawVec<T, VEC> Q[PD > 1 ? PD - 1 : 1], HL[PD], HH[PD];
+#pragma unroll
+    for (int k = 0; k < PD - 1; ++k) Q[k] = src.raw((int64_t)min(x0 + 2 + k, x1) * sx + m);
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {
+      HL[k] = RawVec<T, VEC>{};
+      HH[k] = RawVec<T, VEC>{};
+      if (LDS && hofs < Nz) {
+        const int64_t hp = (int64_t)min(x0 + 1 + k, x1) * sx + m0;
+        HL[k] = src.raw(hp - Nz + hofs);
+        HH[k] = src.raw(hp + tile_len + hofs);
+      }
     }
 
     for (int x = x0; x < x1; ++x) {
@@ -328,17 +350,17 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       // waits for them where they are consumed (the rotation below), not here.
       const int64_t nn = more ? nb : base;                  // plane x+1 (or x again on the last step)
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
-      const vec_t<T, VEC> vpp = src.ld(n2);
+      const RawVec<T, VEC> qn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + m);   // operand vector, plane x+1+PD
       // plane x+1's coefficients (class known since the previous step); class of plane x+2
       CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls);
       if (!COMP) cn.cxm = cc.cxp;                           // cx[x+1] was this step's upper-face weight
       unsigned char cls_nn = kClsMixed;
       if (COMP) cls_nn = cls[n2 / VEC];
-      vec_t<T, VEC> hlo_n = {}, hhi_n = {};                           // halos of plane x+2, published one step later
+      RawVec<T, VEC> hln = {}, hhn = {};                    // halo rows of plane x+1+PD
       if (LDS && hofs < Nz) {
-        const int64_t hp = (int64_t)(more ? x + 2 : x + 1) * sx + m0;
-        hlo_n = src.ld(hp - Nz + hofs);
-        hhi_n = src.ld(hp + tile_len + hofs);
+        const int64_t hp = (int64_t)min(x + 1 + PD, x1) * sx + m0;
+        hln = src.raw(hp - Nz + hofs);
+        hhn = src.raw(hp + tile_len + hofs);
       }
       // ---- in-plane neighbours of plane x
       vec_t<T, VEC> vym, vyp;
@@ -368,8 +390,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
           T* bn = smem + (cur ^ 1) * buf_elems;
           if (active) vstore<T, VEC>(bn + Nz + tid * VEC, vp);
           if (hofs < Nz) {
-            vstore<T, VEC>(bn + hofs, hlo);
-            vstore<T, VEC>(bn + Nz + tile_len + hofs, hhi);
+            vstore<T, VEC>(bn + hofs, src.fin(HL[0]));
+            vstore<T, VEC>(bn + Nz + tile_len + hofs, src.fin(HH[0]));
           }
           for (int h = hofs + kApplyBlock * VEC; h < Nz; h += kApplyBlock * VEC) {   // rows longer than one tile
             vstore<T, VEC>(bn + h, src.ld((int64_t)(x + 1) * sx + m0 - Nz + h));
@@ -377,8 +399,13 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
           }
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        vm = vc; vc = vp; vp = vpp; cc = cn; cls_n = cls_nn;
-        hlo = hlo_n; hhi = hhi_n;
+        vm = vc; vc = vp; vp = src.fin(PD == 1 ? qn : Q[0]); cc = cn; cls_n = cls_nn;
+#pragma unroll
+        for (int k = 0; k + 1 < PD - 1; ++k) Q[k] = Q[k + 1];
+        if (PD > 1) Q[PD - 2] = qn;
+#pragma unroll
+        for (int k = 0; k + 1 < PD; ++k) { HL[k] = HL[k + 1]; HH[k] = HH[k + 1]; }
+        HL[PD - 1] = hln; HH[PD - 1] = hhn;
         base = nb;
       }
     }

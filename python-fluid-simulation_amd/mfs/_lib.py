@@ -72,6 +72,7 @@ SIGNATURES = {
     "mfs_pcg3d_tune": (_i, [_p, _i, _i, _i, _i]),
     "mfs_pcg3d_set_compress": (_i, [_p, _i]),
     "mfs_pcg3d_set_fuse": (_i, [_p, _i]),
+    "mfs_pcg3d_set_prefetch": (_i, [_p, _i]),
     "mfs_visc_extrapolate3d_workspace_bytes": (_sz, [_pi64, _i]),
     "mfs_visc_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _i, _p, _sz, _p]),
     "mfs_visc_rhs3d": (_i, [_pi64, _d, _d, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),

@@ -46,6 +46,9 @@ class PcgEngine:
         _lib.check(self.lib.mfs_pcg3d_tune(self.h, int(variant), int(xchunk), int(blocks_per_cu), int(nontemporal)),
                    "mfs_pcg3d_tune")
 
+    def set_prefetch(self, planes):
+        _lib.check(self.lib.mfs_pcg3d_set_prefetch(self.h, int(planes)), "mfs_pcg3d_set_prefetch")
+
     def set_fuse(self, on):
         _lib.check(self.lib.mfs_pcg3d_set_fuse(self.h, int(bool(on))), "mfs_pcg3d_set_fuse")
 

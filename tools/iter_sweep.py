@@ -20,11 +20,13 @@ P.initialize_solver(sc["cell_size"], gres, sc["vx"], sc["vy"], sc["vz"], sc["sph
 eng = PcgEngine(gres, dt, dev); eng.setup(sc["lphi"], wx, wy, wz); eng.bind(b, x, d, r, q)
 del sc; torch.cuda.empty_cache()
 # config = "variant,bpc,nt,compress" strings
-cfgs = sys.argv[4:] or ["2,2,15,1", "3,2,15,1", "3,1,15,1", "4,1,15,1", "3,2,15,0", "4,1,15,0"]
+# config = "variant,bpc,nt,compress[,fuse,pd]"
+cfgs = sys.argv[4:] or ["2,2,15,1,1,2", "2,2,15,1,1,1", "2,2,15,1,0,2", "2,2,15,1,0,1", "2,2,15,0,1,2", "2,2,15,0,0,2"]
 ref = None
 for c in cfgs:
-    var, bpc, nt, comp = (int(t) for t in c.split(","))
-    eng.set_compress(comp)
+    f = [int(t) for t in c.split(",")] + [1, 2]
+    var, bpc, nt, comp, fuse, pd = f[:6]
+    eng.set_compress(comp); eng.set_fuse(fuse); eng.set_prefetch(pd)
     eng.tune(var, 0, bpc, nt)
     eng.begin(0.0); eng.iterate(10); torch.cuda.synchronize()
     t0 = time.perf_counter(); eng.iterate(iters); torch.cuda.synchronize(); t = (time.perf_counter() - t0) / iters
@@ -33,4 +35,4 @@ for c in cfgs:
     for _ in range(20): eng.apply(d, o)
     e_.record(); torch.cuda.synchronize()
     if ref is None: ref = o.clone()
-    print(f"variant {var} bpc {bpc} nt {nt:2d} compress {comp}: {t*1e6:8.2f} us/iter  {N**3/t/1e9:7.2f} Gcell/s   apply b2b {a_.elapsed_time(e_)/20*1e3:7.2f} us  equal={torch.equal(o, ref)}", flush=True)
+    print(f"variant {var} bpc {bpc} nt {nt:2d} compress {comp} fuse {fuse} pd {pd}: {t*1e6:8.2f} us/iter  {N**3/t/1e9:7.2f} Gcell/s   apply b2b {a_.elapsed_time(e_)/20*1e3:7.2f} us  equal={torch.equal(o, ref)}", flush=True)
