@@ -28,6 +28,9 @@
 #pragma once
 #include "mfs_common.h"
 
+// workgroup barrier that waits on LDS traffic only: global prefetches stay in flight across it
+#define MFS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 namespace mfs {
 
 constexpr int kApplyBlock = 256;
@@ -133,8 +136,8 @@ k_pcg_apply_direct(const T* __restrict__ v, T* __restrict__ out, const T* __rest
 // surface) or anything else (MIXED).  Only MIXED vectors read the four coefficient
 // arrays; the others are reconstructed from the class, bit-identically.  In a
 // fluid solve almost every vector is ZERO or REGULAR, so the kernel's HBM traffic
-// drops from 6 to ~2.5 scalars per cell.  Lanes of non-MIXED vectors aim their
-// (unconditional, branch-free) loads at one dummy line so they cost no bandwidth.
+// drops from 6 to ~2.5 scalars per cell.  Lanes of non-MIXED vectors issue no
+// coefficient request at all (exec-masked loads over class constants).
 enum : unsigned char { kClsZero = 0, kClsRegular = 1, kClsMixed = 2 };
 
 template <typename T, int VEC>
@@ -149,28 +152,30 @@ __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag,
                                                      int64_t b, int64_t sx, int Nz, unsigned char cls) {
   CoefVec<T, VEC> c;
   c.cls = cls;
-  const bool real = !COMP || cls == kClsMixed;
-  // dummy target: the first vector of `diag` (always mapped, 16-byte aligned)
-  const int64_t o0 = real ? b : 0, o1 = real ? b + sx : 0, o2 = real ? b + Nz : 0;
-  c.dg = (NT & 1) ? vload_nt<T, VEC>(diag + o0) : vload<T, VEC>(diag + o0);
-  if (COMP) c.cxm = vload<T, VEC>((real ? cx : diag) + o0);   // dense mode carries cx[x] over from the previous step
-  else c.cxm = c.dg;
-  c.cxp = (NT & 2) ? vload_nt<T, VEC>((real ? cx : diag) + o1) : vload<T, VEC>((real ? cx : diag) + o1);
-  c.cym = (NT & 4) ? vload_nt<T, VEC>((real ? cy : diag) + o0) : vload<T, VEC>((real ? cy : diag) + o0);
-  c.cyp = (NT & 4) ? vload_nt<T, VEC>((real ? cy : diag) + o2) : vload<T, VEC>((real ? cy : diag) + o2);
-  c.czm = (NT & 1) ? vload_nt<T, VEC>((real ? cz : diag) + o0) : vload<T, VEC>((real ? cz : diag) + o0);
-  return c;
-}
-
-// effective coefficients at use time (after the loads have landed)
-template <typename T, int VEC, bool COMP>
-__device__ __forceinline__ void coef_resolve(CoefVec<T, VEC>& c) {
-  if (!COMP) return;
-  if (c.cls != kClsMixed) {
-    const T f = c.cls == kClsRegular ? (T)1 : (T)0, d = c.cls == kClsRegular ? (T)6 : (T)0;
+  if (COMP) {
+    // class constants first (every lane), then an exec-masked overwrite for the MIXED lanes only: lanes
+    // of ZERO / REGULAR vectors issue no memory request at all, and nothing after the branch reads the
+    // loaded registers, so the loads stay in flight until the stencil consumes them.
+    const T f = cls == kClsRegular ? (T)1 : (T)0, d = cls == kClsRegular ? (T)6 : (T)0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { c.dg[j] = d; c.cxm[j] = f; c.cxp[j] = f; c.cym[j] = f; c.cyp[j] = f; c.czm[j] = f; }
+    if (cls == kClsMixed) {
+      c.dg = (NT & 1) ? vload_nt<T, VEC>(diag + b) : vload<T, VEC>(diag + b);
+      c.cxm = vload<T, VEC>(cx + b);
+      c.cxp = (NT & 2) ? vload_nt<T, VEC>(cx + b + sx) : vload<T, VEC>(cx + b + sx);
+      c.cym = (NT & 4) ? vload_nt<T, VEC>(cy + b) : vload<T, VEC>(cy + b);
+      c.cyp = (NT & 4) ? vload_nt<T, VEC>(cy + b + Nz) : vload<T, VEC>(cy + b + Nz);
+      c.czm = (NT & 1) ? vload_nt<T, VEC>(cz + b) : vload<T, VEC>(cz + b);
+    }
+    return c;
   }
+  c.dg = (NT & 1) ? vload_nt<T, VEC>(diag + b) : vload<T, VEC>(diag + b);
+  c.cxm = c.dg;                                             // dense mode carries cx[x] over from the previous step
+  c.cxp = (NT & 2) ? vload_nt<T, VEC>(cx + b + sx) : vload<T, VEC>(cx + b + sx);
+  c.cym = (NT & 4) ? vload_nt<T, VEC>(cy + b) : vload<T, VEC>(cy + b);
+  c.cyp = (NT & 4) ? vload_nt<T, VEC>(cy + b + Nz) : vload<T, VEC>(cy + b + Nz);
+  c.czm = (NT & 1) ? vload_nt<T, VEC>(cz + b) : vload<T, VEC>(cz + b);
+  return c;
 }
 
 // class of every z-vector from the dense coefficient arrays (once per solve)
@@ -321,7 +326,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
         vstore<T, VEC>(b0 + h, src.ld((int64_t)x0 * sx + m0 - Nz + h));
         vstore<T, VEC>(b0 + Nz + tile_len + h, src.ld((int64_t)x0 * sx + m0 + tile_len + h));
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      MFS_LDS_BARRIER();
     }
     // in flight from here on: the operand vector of planes x0+2 .. x0+PD and the halo rows of planes
     // x0+1 .. x0+PD (raw; consumed PD steps after issue)
@@ -378,7 +383,6 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
         zl = (double)((lane == 0 && !first) ? v[base - 1] : l);
         zr = (double)((lane == 63 && !last) ? v[base + VEC] : r);
       }
-      coef_resolve<T, VEC, COMP>(cc);
       const T czs = __shfl_down(cc.czm[0], 1, 64);
       const double czr = (double)((lane == 63 && !last) ? cz[base + VEC] : czs);
       stencil_vec<T, VEC>(out + base, vc, vp, vm, vyp, vym, cc.dg, cc.cxp, cc.cxm, cc.cyp, cc.cym, cc.czm, zl, zr, czr,
@@ -397,7 +401,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
             vstore<T, VEC>(bn + h, src.ld((int64_t)(x + 1) * sx + m0 - Nz + h));
             vstore<T, VEC>(bn + Nz + tile_len + h, src.ld((int64_t)(x + 1) * sx + m0 + tile_len + h));
           }
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          MFS_LDS_BARRIER();
         }
         vm = vc; vc = vp; vp = src.fin(PD == 1 ? qn : Q[0]); cc = cn; cls_n = cls_nn;
 #pragma unroll
@@ -409,7 +413,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
         base = nb;
       }
     }
-    if (LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // next work unit reuses buffer 0
+    if (LDS) MFS_LDS_BARRIER();  // next work unit reuses buffer 0
   }
   const double tot = block_sum<kApplyBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -497,7 +501,7 @@ k_pcg_apply_march_r(const T* __restrict__ v, T* __restrict__ out, const T* __res
         vstore<T, VEC>(b0 + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 - Nz + h));
         vstore<T, VEC>(b0 + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 + tile_len + h));
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      MFS_LDS_BARRIER();
     }
     vec_t<T, VEC> hlo = {}, hhi = {};                       // halo vectors of plane x0+1
     if (hofs < Nz) {
@@ -537,7 +541,6 @@ k_pcg_apply_march_r(const T* __restrict__ v, T* __restrict__ out, const T* __res
         const vec_t<T, VEC> vym = vload<T, VEC>(bc + lo);
         const vec_t<T, VEC> vyp = vload<T, VEC>(bc + 2 * Nz + lo);
         const double zl = (double)bc[Nz + lo - 1], zr = (double)bc[Nz + lo + VEC];
-        coef_resolve<T, VEC, COMP>(cc[r]);
         const T czs = __shfl_down(cc[r].czm[0], 1, 64);
         const double czr = (double)((lane == 63 && !last[r]) ? cz[base[r] + VEC] : czs);
         stencil_vec<T, VEC>(out + base[r], vc[r], vp[r], vm[r], vyp, vym, cc[r].dg, cc[r].cxp, cc[r].cxm, cc[r].cyp,
@@ -557,7 +560,7 @@ k_pcg_apply_march_r(const T* __restrict__ v, T* __restrict__ out, const T* __res
           vstore<T, VEC>(bn + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 - Nz + h));
           vstore<T, VEC>(bn + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 + tile_len + h));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        MFS_LDS_BARRIER();
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
           vm[r] = vc[r]; vc[r] = vp[r]; vp[r] = vpp[r]; cc[r] = cn[r]; cls_n[r] = cls_nn[r];
@@ -566,7 +569,7 @@ k_pcg_apply_march_r(const T* __restrict__ v, T* __restrict__ out, const T* __res
         hlo = hlo_n; hhi = hhi_n;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // next work unit reuses buffer 0
+    MFS_LDS_BARRIER();   // next work unit reuses buffer 0
   }
   const double tot = block_sum<kApplyBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
