@@ -38,7 +38,8 @@ typedef enum {
   MFS_NOT_CONVERGED = 1,  /* reference: raise ValueError("Failed to converge!"), PressureCGSolver3D.py:222-223 */
   MFS_E_INVALID = -1,     /* bad argument (null pointer, bad dtype, bad size, misuse) */
   MFS_E_HIP = -2,         /* a HIP runtime call failed; see mfs_last_error() */
-  MFS_E_NODEVICE = -3     /* no gfx950 device visible */
+  MFS_E_NODEVICE = -3,    /* no gfx950 device visible */
+  MFS_E_TIMEOUT = -4      /* slab loop: a peer GPU did not answer within MFS_P2P_TIMEOUT_MS; the solve was stopped */
 } mfs_status;
 
 typedef void* mfs_stream; /* hipStream_t */
@@ -153,6 +154,7 @@ int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream);
 #define MFS_PCG_S_ALPHA 6
 #define MFS_PCG_S_BETA 7
 #define MFS_PCG_S_LASTRR 8  /* r.r of the last completed iteration (what the reference keeps in self.delta) */
+#define MFS_PCG_S_ERR 11    /* != 0: a peer-to-peer wait of the slab loop timed out */
 void* mfs_pcg3d_scalars(mfs_pcg3d* h);
 /* performance knobs of the stencil kernel (results are identical for every setting):
  * variant 0 = direct loads, 1 = x-marching in registers, 2 = x-marching + LDS-staged
@@ -170,6 +172,47 @@ int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
 int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on);
 /* planes of the operand stream the LDS march keeps in flight ahead of the plane it computes (1 or 2) */
 int mfs_pcg3d_set_prefetch(mfs_pcg3d* h, int planes);
+
+/* ------------------------------------------------------------------------- */
+/* Pressure, 3D -- slab-decomposed CG over peer-to-peer windows (multi-GPU)     */
+/* ------------------------------------------------------------------------- */
+/* New design (the reference is single-GPU): one process per GPU, the grid cut into
+ * x-slabs (mfs/dist.py).  A window is a block of uncached device memory per rank that
+ * the other ranks of the node map through HIP IPC; inside the CG loop the edge planes of
+ * the direction vector and the two dot products travel as plain xGMI stores issued by
+ * the solver's own kernels (csrc/mfs_p2p.h, csrc/mfs_pcg_slab.h) -- no host round trip
+ * and no collective call per iteration.  EXCEPTION to "nothing allocates behind the
+ * ABI": the window is allocated here, because IPC-exportable uncached memory cannot be
+ * carved from a caller's sub-allocator.                                             */
+typedef struct mfs_p2p mfs_p2p;
+/* size of the opaque IPC handle mfs_p2p_create writes (hipIpcMemHandle_t) */
+size_t mfs_p2p_handle_bytes(void);
+/* host call: allocate this rank's window for halo planes of `plane_bytes` (= Ny*Nz*sizeof
+ * element) and write its IPC handle to handle_out_host (mfs_p2p_handle_bytes() bytes)  */
+int mfs_p2p_create(mfs_p2p** out_host, int rank, int world, size_t plane_bytes, void* handle_out_host);
+/* host call: map the peers' windows; handles_host = world handles in rank order (all-gathered by the caller) */
+int mfs_p2p_connect(mfs_p2p* p, const void* handles_host);
+/* COLLECTIVE, host-synchronous: every rank sends a patterned plane to its neighbours, raises the
+ * flags, takes part in one all-reduce through the windows and verifies what it received.
+ * ok_host = 1 only if everything arrived intact within the time limit; detail_host (4 words,
+ * optional): ok, mismatching payload words, timeout bits, all-reduce sum as float bits          */
+int mfs_p2p_selftest(mfs_p2p* p, int round, mfs_stream stream, int* ok_host, unsigned* detail_host);
+/* alloc_kind: 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained */
+int mfs_p2p_info(mfs_p2p* p, int* alloc_kind_host, size_t* window_bytes_host);
+/* host call; every rank must have finished using the windows (barrier first) */
+int mfs_p2p_destroy(mfs_p2p* p);
+
+/* let the engine run its slab loop over this window (null detaches) */
+int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p);
+/* the slab loop: begin / iterate / solve with the semantics of mfs_pcg3d_begin / _iterate /
+ * _solve on the GLOBAL grid; COLLECTIVE -- every rank of the window calls them in step.
+ * The engine's grid is this rank's slab incl. one ghost / boundary plane each side.
+ * A peer that does not answer within MFS_P2P_TIMEOUT_MS (default 3000) stops the solve:
+ * the next poll / solve returns MFS_E_TIMEOUT.                                          */
+int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream);
+int mfs_pcg3d_slab_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream);
+int mfs_pcg3d_slab_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_every,
+                         mfs_stream stream, int64_t* iters_host);
 
 /* ------------------------------------------------------------------------- */
 /* Viscosity, 3D -- stateless kernels (the reference's module-level functions) */

@@ -39,7 +39,8 @@ constexpr int64_t kHistCap = 16384;
 
 enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TOL2 = MFS_PCG_S_TOL2,
        S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
-       S_LASTRR = MFS_PCG_S_LASTRR, S_RING = 9 /* 2 slots: delta by iteration parity */ };
+       S_LASTRR = MFS_PCG_S_LASTRR, S_RING = 9 /* 2 slots: delta by iteration parity */,
+       S_ERR = MFS_PCG_S_ERR /* != 0: a peer-to-peer wait timed out (slab loop); the solve is stopped */ };
 
 
 template <typename T, int VEC>
@@ -268,13 +269,6 @@ static __global__ void k_begin_finish(double* scal, double* hist) {
 
 
 // ------------------------------------------------------------- host side ----
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-static inline int env_int(const char* name, int defv) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : defv;
-}
-
 // The flat CG state of one engine: n DOFs of dtype dt in five caller-owned vectors.
 struct CgCore {
   int dt = MFS_F64;
@@ -420,7 +414,7 @@ static inline int core_begin_pre(CgCore& c, double tol, bool zero_x, hipStream_t
 }
 
 // begin, part 2 (after q = A x): d = r = b - q, partial r.r, reduce -> scalars[RR]
-static inline int core_begin_post(CgCore& c, hipStream_t st) {
+static inline int core_begin_post(CgCore& c, hipStream_t st, bool reduce = true) {
   const bool vec = core_vec_ok(c);
   const int g2 = core_vec_grid(c, vec);
   if (c.dt == MFS_F32) {
@@ -432,7 +426,7 @@ static inline int core_begin_post(CgCore& c, hipStream_t st) {
   }
   MFS_LAUNCH_CHECK();
   c.n_part_rr = g2;
-  return core_reduce(c, 1, 0, st);
+  return reduce ? core_reduce(c, 1, 0, st) : MFS_OK;
 }
 
 static inline int core_begin_finish(CgCore& c, hipStream_t st) {
@@ -445,6 +439,10 @@ static inline int core_poll(CgCore& c, hipStream_t st, int64_t* iters, int* done
                             double* beta) {
   MFS_HIP_TRY(hipMemcpyAsync(c.pinned, c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
   MFS_HIP_TRY(hipStreamSynchronize(st));
+  if (c.pinned[S_ERR] != 0.0) {
+    set_error("peer-to-peer wait timed out inside the CG loop (code %d: 1 = all-reduce, 2 = halo plane)", (int)c.pinned[S_ERR]);
+    return MFS_E_TIMEOUT;
+  }
   if (iters) *iters = (int64_t)c.pinned[S_ITERS];
   if (done) *done = c.pinned[S_DONE] != 0.0;
   if (delta) *delta = c.pinned[S_LASTRR];

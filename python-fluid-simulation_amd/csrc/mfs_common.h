@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include "../../include/mfs.h"
 
@@ -99,5 +102,12 @@ template <> struct VecOf<float> { static constexpr int N = 4; };
 template <> struct VecOf<double> { static constexpr int N = 2; };
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// integer knob from the environment (tuning / test hooks only)
+static inline int env_int(const char* name, int defv) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : defv;
+}
 
 }  // namespace mfs

@@ -14,6 +14,7 @@
 // cell as the reference formulation (v, lphi, wx, wy, wz -> out).
 #include "mfs_cg_core.h"
 #include "mfs_pcg_apply.h"
+#include "mfs_pcg_slab.h"
 
 namespace mfs {
 
@@ -77,6 +78,7 @@ struct mfs_pcg3d {
   int variant, xchunk, nt, bpc, nt_auto;   // apply-kernel tuning (mfs_pcg3d_tune)
   bool vec_ok;
   bool is_setup;
+  mfs_p2p* p2p;                // peer-to-peer window of the slab loop (mfs_pcg3d_attach_p2p), or null
 };
 
 // Coefficient arrays are staggered by an odd number of 4 KiB pages so that the six
@@ -239,6 +241,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->bpc = env_int("MFS_APPLY_BLOCKS_PER_CU", 2);
   h->grid_apply = std::min(kMaxPartials, h->cus * 8);
   h->is_setup = false;
+  h->p2p = nullptr;
   if (hipMemsetAsync(workspace, 0, mfs_pcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
     set_error("hipMemsetAsync(workspace) failed");
     core_free(h->c);
@@ -508,6 +511,139 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
 int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_stream stream) {
   if (!h) { set_error("mfs_pcg3d_history: null handle"); return MFS_E_INVALID; }
   return core_history(h->c, out_host, cap, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ----------------------------------------------------------------------------------------------
+// Slab loop over peer-to-peer windows (mfs_pcg_slab.h): one rank of a grid cut into x-slabs.
+// ----------------------------------------------------------------------------------------------
+static bool slab_ok(const mfs_pcg3d* h) {
+  return h->p2p && h->p2p->connected && native_fuse_ok(h) &&
+         (size_t)h->Ny * h->Nz * h->c.elt == h->p2p->plane_bytes;
+}
+
+static unsigned slab_ar_tag(const mfs_p2p* p, int64_t episode) {
+  return 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)(episode & 0xfffff);
+}
+
+template <int WHICH>
+static int slab_allreduce(mfs_pcg3d* h, const double* partial, int count, int64_t episode, hipStream_t st) {
+  hipLaunchKernelGGL((k_slab_allreduce<WHICH>), dim3(1), dim3(kBlock), 0, st, partial, count, h->c.scal, h->c.hist,
+                     kHistCap, (int)(h->c.iter_enq & 1), h->p2p->dev, (int)(episode & (kArRing - 1)),
+                     slab_ar_tag(h->p2p, episode));
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+template <typename T>
+static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
+  constexpr int VEC = VecOf<T>::N;
+  mfs_p2p* p = h->p2p;
+  const int64_t j = h->c.iter_enq;
+  const int par = (int)(j & 1), L = h->Nx;
+  T* d_cur = (T*)((j & 1) ? h->d2 : h->c.d);
+  T* d_prev = (T*)((j & 1) ? h->c.d : h->d2);
+  const SlabEdge e = slab_edges(L, p->rank, p->world);
+  const int64_t plane_elems = (int64_t)h->Ny * h->Nz;
+  const u64 halo_tag = ((u64)p->epoch << 32) | (u64)(j + 1);
+  unsigned* ticket = p->local;
+  int e_;
+  // 1. edge planes of d_j: local + into the neighbours' windows
+  if (e.np > 0) {
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->cus, (plane_elems / VEC + kBlock - 1) / kBlock));
+    if (j == 0)
+      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, true>), dim3(grid), dim3(kBlock), 0, st, (const T*)nullptr, (const T*)d_cur,
+                         (T*)nullptr, plane_elems, e, h->c.scal, p->dev, par, halo_tag, ticket);
+    else
+      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, false>), dim3(grid), dim3(kBlock), 0, st, (const T*)h->c.r, (const T*)d_prev,
+                         d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag, ticket);
+    MFS_LAUNCH_CHECK();
+  }
+  // 2. planes that touch no ghost, while the edge planes travel
+  int n_part = 0;
+  if (L - 2 > 2) {
+    int grid = 0;
+    if (j == 0) {
+      if ((e_ = apply_dispatch(h, d_cur, h->c.q, 2, L - 2, h->c.part_dq, 1, st, &grid))) return e_;
+    } else {
+      FuseArgs fz{h->c.r, d_prev, d_cur};
+      if ((e_ = apply_dispatch(h, d_cur, h->c.q, 2, L - 2, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e_;
+    }
+    n_part = grid;
+  }
+  // 3. edge planes of q (ghost operands from the own window)
+  if (e.np > 0) {
+    const int64_t items = (int64_t)e.np * (h->Ny - 2) * (h->Nz / VEC);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (items + kApplyBlock - 1) / kApplyBlock));
+    hipLaunchKernelGGL((k_slab_edge_apply<T, VEC>), dim3(grid), dim3(kApplyBlock), 0, st, (const T*)d_cur, (T*)h->c.q,
+                       (const T*)h->diag, (const T*)h->cx, (const T*)h->cy, (const T*)h->cz, L, h->Ny, h->Nz, e,
+                       h->c.part_dq + n_part, h->c.scal, p->dev, par, halo_tag);
+    MFS_LAUNCH_CHECK();
+    n_part += grid;
+  }
+  h->c.n_part_dq = n_part;
+  // 4. d.q over all ranks   5. x, r update   6. r.r over all ranks + bookkeeping (closes the iteration)
+  if ((e_ = slab_allreduce<0>(h, h->c.part_dq, n_part, 2 * j + 1, st))) return e_;
+  if ((e_ = core_update_xr(h->c, false, st, 0, d_cur))) return e_;
+  if ((e_ = slab_allreduce<1>(h, h->c.part_rr, h->c.n_part_rr, 2 * j + 2, st))) return e_;
+  ++h->c.iter_enq;
+  return MFS_OK;
+}
+
+extern "C" {
+
+int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p) {
+  MFS_REQUIRE(h, "null handle");
+  if (p) {
+    MFS_REQUIRE(p->connected, "mfs_p2p_connect has not been called");
+    MFS_REQUIRE((size_t)h->Ny * h->Nz * h->c.elt == p->plane_bytes, "window plane size != Ny*Nz*sizeof(element)");
+  }
+  h->p2p = p;
+  return MFS_OK;
+}
+
+int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  MFS_REQUIRE(slab_ok(h), "slab loop needs an attached window, the vector path (Nz % 4 (fp32) / 2 (fp64) == 0, 16-byte aligned CG vectors) and stencil variant 2");
+  hipStream_t st = (hipStream_t)stream;
+  ++h->p2p->epoch;
+  if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
+  int grid = 0;
+  if (int e = apply_dispatch(h, h->c.x, h->c.q, 1, h->Nx - 1, h->c.part_dq, 0, st, &grid)) return e;  // q = A x (:201)
+  if (int e = core_begin_post(h->c, st, false)) return e;             // d = r = b - q, partials of r.r
+  if (int e = slab_allreduce<2>(h, h->c.part_rr, h->c.n_part_rr, 0, st)) return e;
+  return core_begin_finish(h->c, st);
+}
+
+int mfs_pcg3d_slab_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  MFS_REQUIRE(slab_ok(h), "slab loop not available for this engine (see mfs_pcg3d_slab_begin)");
+  for (int64_t i = 0; i < n; ++i) {
+    const int e = h->dt == MFS_F32 ? slab_iteration<float>(h, (hipStream_t)stream)
+                                   : slab_iteration<double>(h, (hipStream_t)stream);
+    if (e) return e;
+  }
+  return MFS_OK;
+}
+
+int mfs_pcg3d_slab_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_every, mfs_stream stream,
+                         int64_t* iters_host) {
+  MFS_REQUIRE(h, "null handle");
+  MFS_REQUIRE(max_iter >= 0 && check_every >= 1, "max_iter / check_every");
+  if (int e = mfs_pcg3d_slab_begin(h, tol, stream)) return e;
+  int64_t enq = 0, iters = 0;
+  int done = 0;
+  if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  while (!done && enq < max_iter) {       // every rank sees the same `done` at the same iteration: same loop everywhere
+    const int64_t n = std::min(check_every, max_iter - enq);
+    if (int e = mfs_pcg3d_slab_iterate(h, n, stream)) return e;
+    enq += n;
+    if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  }
+  if (int e = pcg_home_d(h, iters, done != 0, (hipStream_t)stream)) return e;
+  if (iters_host) *iters_host = iters;
+  return done ? MFS_OK : MFS_NOT_CONVERGED;
 }
 
 }  // extern "C"

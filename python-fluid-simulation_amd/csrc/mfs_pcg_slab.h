@@ -1,0 +1,161 @@
+// mfs_pcg_slab.h -- kernels of the slab-decomposed (multi-GPU) pressure CG loop that talk
+// to the neighbours' windows directly (mfs_p2p.h).  One iteration j on every rank, all on
+// ONE stream, no host synchronisation and no library collective inside the loop:
+//
+//   k_slab_edge_d       d_j = r + beta d_{j-1} on the two edge planes {1, L-2}; each plane
+//                       is stored locally AND into the neighbour's window, then flagged
+//   <stencil launch>    planes [2, L-2): the single-GPU LDS march with the direction update
+//                       folded in (mfs_pcg_apply.h) -- runs while the edge planes travel
+//   k_slab_edge_apply   q on the two edge planes, ghost plane read from the own window
+//                       once the neighbour's flag has arrived; d.q partials
+//   k_slab_allreduce    local partials -> every rank's window -> sum in rank order -> d.q
+//   k_update_xr         alpha, x += alpha d, r -= alpha q, r.r partials   (mfs_cg_core.h)
+//   k_slab_allreduce    r.r, then the convergence test / history / beta bookkeeping
+//
+// The arithmetic of every cell is the single-GPU kernels' (same stencil_vec, same update
+// expressions), so a slab solve differs from the single-domain one only in the order in
+// which the dot products' partial sums are added.
+#pragma once
+#include "mfs_cg_core.h"
+#include "mfs_p2p.h"
+#include "mfs_pcg_apply.h"
+
+namespace mfs {
+
+// the (one or two) edge planes of a slab of L local planes and who receives them
+struct SlabEdge {
+  int np;
+  int plane[2];
+  int to_left[2], to_right[2];   // plane k is the left / right neighbour's ghost
+};
+
+static inline SlabEdge slab_edges(int L, int rank, int world) {
+  SlabEdge e{};
+  const int lo = 1, hi = L - 2;
+  if (hi < lo) return e;
+  e.np = hi > lo ? 2 : 1;
+  e.plane[0] = lo; e.plane[1] = hi;
+  const bool left = rank > 0, right = rank < world - 1;
+  e.to_left[0] = left; e.to_right[0] = (hi == lo) && right;
+  e.to_left[1] = 0;    e.to_right[1] = (hi > lo) && right;
+  return e;
+}
+
+__device__ __forceinline__ void slab_fail(double* scal, int code) {
+  // a peer did not answer: raise the error word and stop the solve (every later kernel returns at its top)
+  __hip_atomic_store(scal + S_ERR, (double)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(scal + S_DONE, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// d_new = r + beta d_old on the edge planes (exactly k_update_d's expression); FIRST: iteration 0,
+// the direction vector is d_old itself and nothing is written locally.
+template <typename T, int VEC, bool FIRST>
+__global__ void __launch_bounds__(kBlock)
+k_slab_edge_d(const T* __restrict__ r, const T* __restrict__ d_old, T* __restrict__ d_new, int64_t plane_elems,
+              SlabEdge e, const double* __restrict__ scal, P2pDev pd, int par, u64 tag, unsigned* ticket) {
+  if (scal[S_DONE] != 0.0) return;
+  const double beta = FIRST ? 0.0 : scal[S_BETA];
+  const int64_t nv = plane_elems / VEC, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int k = 0; k < e.np; ++k) {
+    const int64_t p0 = (int64_t)e.plane[k] * plane_elems;
+    T* const left = e.to_left[k] ? reinterpret_cast<T*>(pd.send[0][par]) : nullptr;
+    T* const right = e.to_right[k] ? reinterpret_cast<T*>(pd.send[1][par]) : nullptr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+      vec_t<T, VEC> dv = vload<T, VEC>(d_old + p0 + i * VEC);
+      if (!FIRST) {
+        const vec_t<T, VEC> rv = vload<T, VEC>(r + p0 + i * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dv[j] = (T)((double)rv[j] + beta * (double)dv[j]);
+        vstore<T, VEC>(d_new + p0 + i * VEC, dv);
+      }
+      if (left) vstore_sys<T, VEC>(left + i * VEC, dv);
+      if (right) vstore_sys<T, VEC>(right + i * VEC, dv);
+    }
+  }
+  publish_planes(ticket, gridDim.x, pd.send_flag[0][par], pd.send_flag[1][par], tag);
+}
+
+// q = A d on the edge planes.  Direct loads (two planes of work: the march's register reuse has
+// nothing to amortise); the x-1 / x+1 operand of a plane next to a neighbour comes from the window.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kApplyBlock)
+k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag, const T* __restrict__ cx,
+                  const T* __restrict__ cy, const T* __restrict__ cz, int L, int Ny, int Nz, SlabEdge e,
+                  double* __restrict__ partial, double* __restrict__ scal, P2pDev pd, int par, u64 tag) {
+  if (scal[S_DONE] != 0.0) return;
+  const bool has_left = pd.rank > 0, has_right = pd.rank < pd.world - 1;
+  const bool ok = await_planes(has_left ? &pd.self->halo_flag[0][par] : nullptr,
+                               has_right ? &pd.self->halo_flag[1][par] : nullptr, tag, pd.timeout_ticks);
+  if (!ok) {
+    if (threadIdx.x == 0) { slab_fail(scal, 2); partial[blockIdx.x] = 0.0; }
+    return;
+  }
+  const T* const ghost_lo = reinterpret_cast<const T*>(pd.recv[0][par]);
+  const T* const ghost_hi = reinterpret_cast<const T*>(pd.recv[1][par]);
+  const int nzv = Nz / VEC;
+  const int64_t ipp = (int64_t)(Ny - 2) * nzv;
+  const int64_t sx = (int64_t)Ny * Nz, sy = Nz;
+  const int64_t items = (int64_t)e.np * ipp, stride = (int64_t)gridDim.x * kApplyBlock;
+  double acc = 0.0;
+  for (int64_t it = (int64_t)blockIdx.x * kApplyBlock + threadIdx.x; it < items; it += stride) {
+    const int px = (int)(it / ipp);
+    const int rem = (int)(it - (int64_t)px * ipp);
+    const int yy = rem / nzv, zv = rem - yy * nzv;
+    const int xx = e.plane[px];
+    const int64_t in_plane = (int64_t)(yy + 1) * sy + (int64_t)zv * VEC;
+    const int64_t base = (int64_t)xx * sx + in_plane;
+    const bool first = zv == 0, last = zv == nzv - 1;
+    const auto vc = vload<T, VEC>(v + base);
+    const auto vxm = (xx == 1 && has_left) ? vload_sys<T, VEC>(ghost_lo + in_plane) : vload<T, VEC>(v + base - sx);
+    const auto vxp = (xx == L - 2 && has_right) ? vload_sys<T, VEC>(ghost_hi + in_plane) : vload<T, VEC>(v + base + sx);
+    const double zl = first ? 0.0 : (double)v[base - 1];
+    const double zr = last ? 0.0 : (double)v[base + VEC];
+    const double czr = last ? 0.0 : (double)cz[base + VEC];
+    stencil_vec<T, VEC>(out + base, vc, vxp, vxm, vload<T, VEC>(v + base + sy), vload<T, VEC>(v + base - sy),
+                        vload<T, VEC>(diag + base), vload<T, VEC>(cx + base + sx), vload<T, VEC>(cx + base),
+                        vload<T, VEC>(cy + base + sy), vload<T, VEC>(cy + base), vload<T, VEC>(cz + base), zl, zr, czr,
+                        first, last, true, acc);
+  }
+  const double tot = block_sum<kApplyBlock>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// ONE block: this rank's partial sums -> every rank's window -> the world's total in rank order.
+// WHICH 0: d.q -> scal[S_DQ].  1: r.r, then the bookkeeping of k_cg_book (convergence test
+// PressureCGSolver3D.py:218, history, iteration count, delta ring, beta :220).  2: the r.r of `begin`.
+template <int WHICH>
+__global__ void __launch_bounds__(kBlock)
+k_slab_allreduce(const double* __restrict__ partial, int count, double* __restrict__ scal, double* __restrict__ hist,
+                 int64_t hist_cap, int par, P2pDev pd, int ring, unsigned tag) {
+  if (WHICH != 2 && scal[S_DONE] != 0.0) return;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) acc += partial[i];
+  const double loc = block_sum<kBlock>(acc);          // thread 0
+  __shared__ double s_loc;
+  if (threadIdx.x == 0) s_loc = loc;
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  ar_send(pd, ring, tag, s_loc, threadIdx.x);
+  bool ok;
+  const double tot = ar_recv(pd, ring, tag, threadIdx.x, &ok);
+  if (threadIdx.x != 0) return;
+  if (!ok) { slab_fail(scal, 1); return; }
+  if (WHICH == 0) {
+    scal[S_DQ] = tot;
+  } else if (WHICH == 2) {
+    scal[S_RR] = tot;
+  } else {
+    const double rr = tot, delta = scal[S_RING + par], dq = scal[S_DQ];
+    const int64_t it = (int64_t)scal[S_ITERS];
+    if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+    scal[S_ITERS] = (double)(it + 1);
+    scal[S_RING + (par ^ 1)] = rr;
+    scal[S_RR] = rr;
+    scal[S_DELTA] = delta;
+    scal[S_LASTRR] = rr;
+    scal[S_ALPHA] = delta / dq;
+    if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rr / delta;
+  }
+}
+
+}  // namespace mfs

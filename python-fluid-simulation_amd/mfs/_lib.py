@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("MFS_LIB") or os.path.join(_HERE, "libmfs_hip.so")   #
 
 MFS_F32, MFS_F64 = 0, 1
 MFS_OK, MFS_NOT_CONVERGED = 0, 1
+MFS_E_TIMEOUT = -4
 ABI_VERSION = 1
 
 # scalar slots of the CG engine's device block (include/mfs.h)
@@ -73,6 +74,16 @@ SIGNATURES = {
     "mfs_pcg3d_set_compress": (_i, [_p, _i]),
     "mfs_pcg3d_set_fuse": (_i, [_p, _i]),
     "mfs_pcg3d_set_prefetch": (_i, [_p, _i]),
+    "mfs_p2p_handle_bytes": (_sz, []),
+    "mfs_p2p_create": (_i, [C.POINTER(_p), _i, _i, _sz, _p]),
+    "mfs_p2p_connect": (_i, [_p, _p]),
+    "mfs_p2p_selftest": (_i, [_p, _i, _p, _pint, C.POINTER(C.c_uint)]),
+    "mfs_p2p_info": (_i, [_p, _pint, C.POINTER(_sz)]),
+    "mfs_p2p_destroy": (_i, [_p]),
+    "mfs_pcg3d_attach_p2p": (_i, [_p, _p]),
+    "mfs_pcg3d_slab_begin": (_i, [_p, _d, _p]),
+    "mfs_pcg3d_slab_iterate": (_i, [_p, _i64, _p]),
+    "mfs_pcg3d_slab_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
     "mfs_visc_extrapolate3d_workspace_bytes": (_sz, [_pi64, _i]),
     "mfs_visc_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _i, _p, _sz, _p]),
     "mfs_visc_rhs3d": (_i, [_pi64, _d, _d, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),

@@ -19,6 +19,11 @@ adds only
   * per iteration: exchange of the two edge planes of `d` with the neighbours
     (interior planes are applied while the planes are in flight), and
   * two scalar all-reduces (d.q and r.r).
+Two transports: "p2p" (default when a window passes its self-test) -- the loop runs
+natively in the library and the planes / dot products move as xGMI stores issued by
+the solver's kernels into HIP-IPC-mapped windows (mfs/p2p.py, csrc/mfs_pcg_slab.h);
+"rccl" -- the phase-by-phase loop below with torch.distributed collectives (RCCL on
+the GPUs, gloo in the CPU tests), which is also the fallback.
 Ghost planes of b, r, q stay exactly 0 (no kernel writes them), so local dot
 products never double count; ghost planes of x accumulate alpha*d_ghost, which is
 the neighbour's own update, so the final velocity update finds p[x-1] in place.
@@ -56,7 +61,7 @@ class SlabCG:
     all-reduces act on.  `d` is the local direction vector (planes 0 and L-1 are
     the ghost / boundary planes).  `dist` is torch.distributed or None (1 rank)."""
 
-    def __init__(self, ops, part, d, dist=None, group=None, overlap=True, force_multi=False):
+    def __init__(self, ops, part, d, dist=None, group=None, overlap=True, force_multi=False, window=None):
         self.ops, self.part, self.d, self.dist, self.group = ops, part, d, dist, group
         self.overlap = overlap
         self.L = int(d.shape[0])
@@ -64,6 +69,16 @@ class SlabCG:
             raise ValueError("d does not match the partition's local plane count")
         # force_multi: take the phase-by-phase path (with its collectives) even on one rank (tests)
         self.multi = dist is not None and (part.world > 1 or force_multi)
+        # window: a connected, self-tested mfs.p2p.P2PWindow -> the loop runs natively inside the library,
+        # halo planes and dot products moving as xGMI stores between the solver's own kernels
+        # (csrc/mfs_pcg_slab.h); without one, the phase-by-phase loop below with RCCL collectives
+        self.window = window if (window is not None and window.ok) else None
+        if self.window is not None:
+            ops.attach_p2p(self.window)
+
+    @property
+    def mode(self):
+        return "p2p" if self.window is not None else ("rccl" if self.multi else "single")
 
     def _allreduce(self, slot):
         self.dist.all_reduce(self.ops.scalars[slot:slot + 1], group=self.group)
@@ -80,6 +95,9 @@ class SlabCG:
         return dist.batch_isend_irecv(ops) if ops else []
 
     def begin(self, tol):
+        if self.window is not None:
+            self.ops.slab_begin(tol)
+            return
         if not self.multi:
             self.ops.begin_local(tol)
             self.ops.begin_finish()
@@ -89,6 +107,9 @@ class SlabCG:
         self.ops.begin_finish()
 
     def iterate(self, n):
+        if self.window is not None:
+            self.ops.slab_iterate(n)
+            return
         if not self.multi:
             self.ops.iterate(n)
             return
@@ -127,7 +148,7 @@ class SlabCG:
 
     def exchange(self, t):
         """one-off halo exchange of another local field (e.g. x before a velocity update)."""
-        if not self.multi:
+        if self.dist is None or self.part.world == 1:
             return
         saved, self.d = self.d, t
         try:

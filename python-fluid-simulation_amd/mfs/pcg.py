@@ -146,3 +146,21 @@ class PcgEngine:
 
     def begin_finish(self):
         _lib.check(self.lib.mfs_pcg3d_begin_finish(self.h, T.stream()), "mfs_pcg3d_begin_finish")
+
+    # -- slab loop over a peer-to-peer window (multi-GPU; COLLECTIVE calls) -----------------
+    def attach_p2p(self, window):
+        _lib.check(self.lib.mfs_pcg3d_attach_p2p(self.h, window.h if window is not None else None),
+                   "mfs_pcg3d_attach_p2p")
+        self._window = window     # keep it alive while the engine points at it
+
+    def slab_begin(self, tol):
+        _lib.check(self.lib.mfs_pcg3d_slab_begin(self.h, float(tol), T.stream()), "mfs_pcg3d_slab_begin")
+
+    def slab_iterate(self, n):
+        _lib.check(self.lib.mfs_pcg3d_slab_iterate(self.h, int(n), T.stream()), "mfs_pcg3d_slab_iterate")
+
+    def slab_solve(self, tol, max_iter, check_every=32):
+        it = C.c_int64()
+        st = _lib.check(self.lib.mfs_pcg3d_slab_solve(self.h, float(tol), int(max_iter), int(check_every), T.stream(),
+                                                      C.byref(it)), "mfs_pcg3d_slab_solve")
+        return st == _lib.MFS_OK, it.value

@@ -1,0 +1,72 @@
+"""Worker of tests/test_p2p_gpu.py: ONE rank of a slab-decomposed pressure solve whose
+ranks all sit on the same MI355X (the GPU box has one card), talking through HIP-IPC
+windows (mfs/p2p.py).  torch.distributed (gloo) only bootstraps the windows.
+usage: p2p_worker.py RANK WORLD PORT GOLDEN_NPZ OUT_PREFIX DTYPE"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "python-fluid-simulation_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from mfs.dist import SlabCG, SlabPartition  # noqa: E402
+from mfs.p2p import P2PWindow  # noqa: E402
+from mfs.pcg import PcgEngine  # noqa: E402
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    path, out, dtname = sys.argv[4], sys.argv[5], sys.argv[6]
+    tdt = {"f64": torch.float64, "f32": torch.float32}[dtname]
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        with np.load(path, allow_pickle=False) as z:
+            g = {k: z[k] for k in z.files}
+        gres = tuple(int(v) for v in g["gres"])
+        part = SlabPartition(gres[0], world, rank)
+        lo, hi = part.local_range
+        lg = (hi - lo, gres[1], gres[2])
+        T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), device=dev).to(dt)  # noqa: E731
+        b = np.array(g["b"][lo:hi], dtype=np.float64)
+        b[0] = 0.0          # ghost / boundary planes carry no equation on this rank
+        b[-1] = 0.0
+        eng = PcgEngine(lg, tdt, dev)
+        eng.setup(T(g["lphi"][lo:hi]), T(g["wx"][lo:hi + 1]), T(g["wy"][lo:hi]), T(g["wz"][lo:hi]))
+        bt = T(b, tdt)
+        x, d, r, q = (torch.zeros(lg, dtype=tdt, device=dev) for _ in range(4))
+        eng.bind(bt, x, d, r, q)
+        win = P2PWindow(dist, lg[1] * lg[2] * bt.element_size(), dev)
+        assert win.ok, win.why
+        cg = SlabCG(eng, part, d, dist, window=win)
+        assert cg.mode == "p2p"
+        reps = int(os.environ.get("P2P_TEST_SOLVES", "1"))
+        for _ in range(reps):            # a second solve re-uses the window (epoch handling)
+            cg.begin(float(g["tol"]))
+            st = eng.poll()
+            n = 0
+            while not st["done"] and n < 4000:
+                cg.iterate(8)
+                n += 8
+                st = eng.poll()
+        torch.cuda.synchronize()
+        xc = x.cpu()                     # gloo moves host tensors; on the GPUs (bench.py) RCCL moves device planes
+        cg.exchange(xc)
+        x.copy_(xc)
+        torch.cuda.synchronize()
+        np.savez(f"{out}.rank{rank}.npz", x=x.cpu().numpy().astype(np.float64), hist=eng.history(),
+                 iters=st["iterations"], done=int(st["done"]), lo=lo, hi=hi, q=q.cpu().numpy().astype(np.float64),
+                 alloc=win.alloc_kind)
+        win.close()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
