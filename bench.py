@@ -35,10 +35,17 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--n", type=int, default=0, help="override: cubic grid edge per GPU (default 256)")
+    ap.add_argument("--local-grid", default="", help="1 GPU experiments: Nx,Ny,Nz of the grid (e.g. 66,512,512 = one rank's slab of the 8-GPU run)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-phases", action="store_true",
                     help="1 GPU: run the phase-by-phase multi-GPU driver loop (1-rank RCCL group) to price its host overhead")
+    ap.add_argument("--transport", default="auto", choices=["auto", "p2p", "rccl"],
+                    help="N>1: how halo planes and dot products travel. p2p = xGMI stores from the solver's kernels into "
+                         "HIP-IPC windows (csrc/mfs_pcg_slab.h); rccl = torch.distributed collectives per iteration; "
+                         "auto = p2p if its self-test and a cross-check against rccl pass, else rccl")
+    ap.add_argument("--force-p2p", action="store_true",
+                    help="1 GPU: run the peer-to-peer slab loop on a 1-rank window to price its launches")
     ap.add_argument("--b2b", action="store_true", help="also time back-to-back applies (cache-warm; not the CG number)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="CG iterations of the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -98,7 +105,7 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.force_phases:
+    if world > 1 or args.force_phases or args.force_p2p:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -117,6 +124,8 @@ def main():
         ggrid = {1: (n, n, n), 2: (2 * n, n, n), 4: (2 * n, 2 * n, n), 8: (2 * n, 2 * n, 2 * n)}[world]
     else:
         ggrid = GRIDS[world]
+    if args.local_grid and world == 1:
+        ggrid = tuple(int(v) for v in args.local_grid.split(","))
     seed = 0
 
     # ---- this rank's slab (global planes [a-1, b+1) incl. one ghost/boundary plane each side)
@@ -137,14 +146,52 @@ def main():
     eng = PcgEngine(lgres, tdt, dev)
     eng.setup(lphi, wx, wy, wz)
     eng.bind(b, x, d, r, q)
-    cg = mdist.SlabCG(eng, part, d, dist if (world > 1 or args.force_phases) else None,
-                      force_multi=args.force_phases)
+    multi = world > 1 or args.force_phases or args.force_p2p
+    cg_rccl = mdist.SlabCG(eng, part, d, dist if multi else None, force_multi=args.force_phases or args.force_p2p)
+    cg, transport, tinfo = cg_rccl, ("rccl" if multi else "single"), {}
 
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def agree(flag):
+        """True only if every rank says so (the ranks must take the same path)."""
+        if world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    window = None
+    if multi and not args.force_phases and args.transport in ("auto", "p2p"):
+        from mfs.p2p import P2PWindow
+        window = P2PWindow(dist, lgres[1] * lgres[2] * esz, dev)
+        tinfo["p2p_selftest"] = "ok" if window.ok else window.why
+        tinfo["p2p_window_memory"] = window.alloc_kind
+        if window.ok:
+            cg_p2p = mdist.SlabCG(eng, part, d, dist, window=window)
+            # cross-check before trusting it for the timed run: the same V iterations from the same
+            # start through both transports must give the same residual history (they differ only
+            # in the order the dot products' partial sums are added)
+            V, dev_rel, ok = 6, float("nan"), False
+            try:
+                cg_rccl.begin(0.0)
+                cg_rccl.iterate(V)
+                h_r = eng.history()[: 2 * V + 1]
+                cg_p2p.begin(0.0)
+                cg_p2p.iterate(V)
+                h_p = eng.history()[: 2 * V + 1]
+                dev_rel = float(abs(h_p - h_r).max() / abs(h_r).max()) if len(h_p) == len(h_r) == 2 * V + 1 else float("nan")
+                ok = dev_rel == dev_rel and max(abs(h_p - h_r) / abs(h_r)) < (1e-5 if args.dtype == "f32" else 1e-9)
+            except _lib.MfsError as exc:
+                tinfo["p2p_error"] = str(exc)[:300]
+            ok = agree(ok)
+            tinfo["p2p_vs_rccl_history_dev"] = dev_rel
+            tinfo["p2p_crosscheck"] = "ok" if ok else "FAILED -> rccl"
+            if ok:
+                cg, transport = cg_p2p, "p2p"
 
     cg.begin(0.0)                          # tol = 0: never "converged", every step does full work
     cg.iterate(args.warmup)
@@ -162,6 +209,19 @@ def main():
     assert st["iterations"] == args.warmup + args.steps, st
     assert st["delta"] == st["delta"], "NaN residual"
 
+    # the other transport on the same problem, outside the timed region (diagnostic only)
+    if world > 1 and transport == "p2p":
+        k_alt = max(10, min(args.steps, 100))
+        cg_rccl.begin(0.0)
+        cg_rccl.iterate(10)
+        sync()
+        t1 = time.perf_counter()
+        cg_rccl.iterate(k_alt)
+        sync()
+        ta = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        tinfo["rccl_transport_ms_per_step"] = round(ta.item() / k_alt * 1e3, 5)
+
     owned_cells = part.global_cells(ggrid)
     value = owned_cells * args.steps / dt / 1e6
 
@@ -173,6 +233,9 @@ def main():
         # SURVEY.md 8(d)'s stencil figure (6N^3+3N^2 scalars: v,4 coefficient arrays in, out) plus the update's
         # r in and d_new out, with d_old taking the place of v = 8N^3+3N^2 scalars per launch
         alg_bytes = (8 * Nx * Ny * Nz + 3 * Ny * Nz) * esz
+        if transport != "single":          # leave the slab loops' state behind: plain single-domain iterations
+            eng.begin(0.0)
+            eng.iterate(2)
         reps = max(20, min(args.steps, 200))
         # inside real CG iterations: HIP events (on the stream the kernel is launched on) bracket each
         # apply launch; an empty event pair is timed the same way for reference
@@ -208,7 +271,7 @@ def main():
         # HBM bytes per launch from PMC counters: collected by tools/pmc_bench.sh on this same command
         # (separate rocprofv3 --pmc passes) and committed under profiles/; valid for the default workload only
         pj = os.path.join(REPO, "profiles", "r01_pmc_apply.json")
-        if os.path.exists(pj) and world == 1 and not args.force_phases:
+        if os.path.exists(pj) and transport == "single":
             try:
                 pm = json.load(open(pj))
                 if pm.get("workload") == f"{Nx}x{Ny}x{Nz} {args.dtype}":
@@ -228,7 +291,7 @@ def main():
     if rank == 0:
         cb = None
         if world == 1 and not args.no_cpu_baseline:
-            del eng, cg, b, x, d, r, q, wx, wy, wz, lphi
+            del eng, cg, cg_rccl, b, x, d, r, q, wx, wy, wz, lphi
             torch.cuda.empty_cache()
             cb = cpu_baseline(args, ggrid, seed)
         iter_bytes = 15 * lgres[0] * lgres[1] * lgres[2] * esz
@@ -242,16 +305,21 @@ def main():
                                    f"PressureCGSolver3D {ggrid[0]}x{ggrid[1]}x{ggrid[2]} synthetic pool scene, fp64 state",
                        "grid": list(ggrid), "cells_per_gpu": lgres[0] * lgres[1] * lgres[2],
                        "decomposition": f"x-slabs x{world}" if world > 1 else "single domain",
+                       "transport": transport,
                        "step": "one CG iteration (apply + 2 dots + x/r/d updates)"},
             "iters_per_s": round(args.steps / dt, 2),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5),
             "cg_iteration_hbm_gbs": round(iter_bytes / (dt / args.steps) / 1e9, 1),
             "roofline": rf,
         }
+        if tinfo:
+            out["transport_info"] = tinfo
         if cb is not None:
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if window is not None:
+        window.close()
+    elif world > 1:
         dist.barrier()
     if dist.is_initialized():
         dist.destroy_process_group()

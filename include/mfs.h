@@ -192,10 +192,10 @@ size_t mfs_p2p_handle_bytes(void);
 int mfs_p2p_create(mfs_p2p** out_host, int rank, int world, size_t plane_bytes, void* handle_out_host);
 /* host call: map the peers' windows; handles_host = world handles in rank order (all-gathered by the caller) */
 int mfs_p2p_connect(mfs_p2p* p, const void* handles_host);
-/* COLLECTIVE, host-synchronous: every rank sends a patterned plane to its neighbours, raises the
- * flags, takes part in one all-reduce through the windows and verifies what it received.
- * ok_host = 1 only if everything arrived intact within the time limit; detail_host (4 words,
- * optional): ok, mismatching payload words, timeout bits, all-reduce sum as float bits          */
+/* COLLECTIVE, host-synchronous: every rank sends a patterned plane to its neighbours, takes part
+ * in one all-reduce through the windows and verifies what it received.  ok_host = 1 only if
+ * everything arrived intact within the time limit; detail_host (4 words, optional): ok, payload
+ * vectors missing or wrong, all-reduce timed out, all-reduce sum as float bits                  */
 int mfs_p2p_selftest(mfs_p2p* p, int round, mfs_stream stream, int* ok_host, unsigned* detail_host);
 /* alloc_kind: 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained */
 int mfs_p2p_info(mfs_p2p* p, int* alloc_kind_host, size_t* window_bytes_host);

@@ -350,20 +350,24 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
 }
 
 #define MFS_XR(TT, VV, NN, MM) \
-  hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x, (const TT*)dsrc, \
-                     (TT*)c.r, (const TT*)c.q, c.n, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), c.part_dq, \
-                     fold ? c.n_part_dq : 0)
+  hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x + off, (const TT*)dsrc + off, \
+                     (TT*)c.r + off, (const TT*)c.q + off, cnt, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), \
+                     c.part_dq, fold ? c.n_part_dq : 0)
 #define MFS_XR_MODE(MM)                                                                                              \
   if (c.dt == MFS_F32) {                                                                                             \
     if (!vec) MFS_XR(float, 1, false, MM); else if (ntx) MFS_XR(float, 4, true, MM); else MFS_XR(float, 4, false, MM); \
   } else {                                                                                                           \
     if (!vec) MFS_XR(double, 1, false, MM); else if (ntx) MFS_XR(double, 2, true, MM); else MFS_XR(double, 2, false, MM); \
   }
-// mode 0: x and r together; 1: r only (+ r.r partials); 2: x only
-static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode = 0, const void* d_override = nullptr) {
+// mode 0: x and r together; 1: r only (+ r.r partials); 2: x only.  [off, off + cnt) restricts the
+// update to a sub-range of the DOFs (the slab loop skips its ghost planes; off a multiple of 16 bytes)
+static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode = 0, const void* d_override = nullptr,
+                                 int64_t off = 0, int64_t cnt = -1) {
   MFS_REQUIRE(c.x, "engine not bound");
   const void* dsrc = d_override ? d_override : c.d;
-  const bool vec = core_vec_ok(c);
+  if (cnt < 0) cnt = c.n - off;
+  MFS_REQUIRE(off >= 0 && cnt >= 0 && off + cnt <= c.n, "update range");
+  const bool vec = core_vec_ok(c) && ((size_t)off * c.elt) % 16 == 0;
   const int grid = core_vec_grid(c, vec);
   const bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
   if (mode == 1) { MFS_XR_MODE(1) } else if (mode == 2) { MFS_XR_MODE(2) } else { MFS_XR_MODE(0) }

@@ -5,16 +5,19 @@
 // HIP IPC.  Inside the CG loop nothing but kernels touches it:
 //
 //   halo planes   the rank that owns an edge plane of the direction vector stores it
-//                 straight into its neighbour's window (write-through stores over
-//                 xGMI), drains, and one lane raises a flag there; the neighbour's
-//                 edge-plane stencil polls that flag, acquires, and reads the plane
-//                 out of its own memory.  Two buffers per side (iteration parity).
+//                 straight into its neighbour's window as self-validating 8-byte
+//                 granules {tag, 32 bits of payload} (one per fp32 cell, two per fp64
+//                 cell): no flag, no fence, no ordering assumption between stores --
+//                 the neighbour's edge-plane stencil reads the granules out of its own
+//                 memory and re-reads any whose tag is not yet this iteration's.  Two
+//                 buffers per side (iteration parity).
 //   dot products  every rank stores its partial sum into a slot of EVERY rank's
 //                 window as two self-validating 8-byte granules {tag, half of the
-//                 double}: no flag, no fence, one xGMI hop.  Each rank adds the world's
-//                 slots in rank order, so all ranks hold the bit-identical sum and
-//                 take identical convergence decisions.
+//                 double}: one xGMI hop.  Each rank adds the world's slots in rank
+//                 order, so all ranks hold the bit-identical sum and take identical
+//                 convergence decisions.
 //
+// The only hardware property relied on is that an aligned 8-byte store is not torn.
 // Every wait is a bounded spin (wall clock); a timeout raises the engine's error word
 // and every later kernel of the solve returns at once, so a lost peer can never hang
 // the GPU.  All cross-GPU accesses are system-scope atomics / fences.
@@ -31,7 +34,6 @@ constexpr size_t kP2pCtrlBytes = 8192;
 
 // Head of every rank's window.  Written ONLY by remote ranks (and zeroed once at creation).
 struct P2pCtrl {
-  u64 halo_flag[2][2];                      // [side 0 = low ghost, 1 = high ghost][parity]: tag of the plane in recv buffer
   u64 ar[kArRing][kP2pMaxWorld][2];         // granules {tag << 32 | half} of rank r's contribution, episode ring
   u64 test_flag[kP2pMaxWorld];              // self-test: token from each rank
 };
@@ -41,9 +43,8 @@ static_assert(sizeof(P2pCtrl) <= kP2pCtrlBytes, "control block too large");
 struct P2pDev {
   P2pCtrl* self;
   P2pCtrl* peer[kP2pMaxWorld];              // peer[rank] == self
-  char* recv[2][2];                         // my receive buffers [side][parity]
-  char* send[2][2];                         // [0]: left neighbour's high-ghost buffers, [1]: right neighbour's low-ghost buffers ([parity]); null = no neighbour
-  u64* send_flag[2][2];                     // the flags that go with them
+  u64* recv[2][2];                          // my receive buffers [side 0 = low ghost, 1 = high ghost][parity], granules
+  u64* send[2][2];                          // [0]: left neighbour's high-ghost buffers, [1]: right neighbour's low-ghost buffers ([parity]); null = no neighbour
   int rank, world;
   u64 timeout_ticks;                        // bound of every spin, in wall-clock ticks (100 MHz)
 };
@@ -53,17 +54,6 @@ __device__ __forceinline__ u64 sys_load(const u64* p) {
 }
 __device__ __forceinline__ void sys_store(u64* p, u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// one lane: poll *p until it equals `want` (relaxed, system scope); false on timeout
-__device__ __forceinline__ bool spin_eq(const u64* p, u64 want, u64 timeout_ticks) {
-  if (sys_load(p) == want) return true;
-  const u64 t0 = wall_clock64();
-  for (;;) {
-    __builtin_amdgcn_s_sleep(2);
-    if (sys_load(p) == want) return true;
-    if (wall_clock64() - t0 > timeout_ticks) return false;
-  }
 }
 
 // ---- scalar all-reduce over the windows --------------------------------------------------
@@ -103,64 +93,62 @@ __device__ __forceinline__ double ar_recv(const P2pDev& pd, int ring, unsigned t
   return tot;
 }
 
-// ---- 16-byte write-through / cache-bypassing accesses for plane payloads ---------------------
-template <typename T, int VEC>
-__device__ __forceinline__ void vstore_sys(T* p, vec_t<T, VEC> v) {
-  static_assert(sizeof(T) * VEC == 16, "payload vectors are 16 bytes");
-  union { vec_t<T, VEC> v; u64 w[2]; } u;
-  u.v = v;
-  sys_store(reinterpret_cast<u64*>(p), u.w[0]);
-  sys_store(reinterpret_cast<u64*>(p) + 1, u.w[1]);
-}
-template <typename T, int VEC>
-__device__ __forceinline__ vec_t<T, VEC> vload_sys(const T* p) {
-  static_assert(sizeof(T) * VEC == 16, "payload vectors are 16 bytes");
-  union { vec_t<T, VEC> v; u64 w[2]; } u;
-  u.w[0] = sys_load(reinterpret_cast<const u64*>(p));
-  u.w[1] = sys_load(reinterpret_cast<const u64*>(p) + 1);
-  return u.v;
-}
+// ---- plane payloads as granules ----------------------------------------------------------------
+// element e of a plane occupies granule(s) [e * G, e * G + G), G = 1 (fp32: the float's bits) or
+// 2 (fp64: low and high half); every granule = tag << 32 | 32 payload bits, written by ONE 8-byte store.
+template <typename T> struct Gran;
+template <> struct Gran<float> { static constexpr int N = 1; };
+template <> struct Gran<double> { static constexpr int N = 2; };
 
-// Publish: call from EVERY thread of the block after its payload stores.  Drains every wave,
-// joins the block, then ONE lane releases at system scope and draws a ticket; the block that
-// draws the last ticket raises the (up to two) remote flags and re-arms the ticket counter.
-__device__ __forceinline__ void publish_planes(unsigned* ticket, unsigned nblocks, u64* flag_a, u64* flag_b, u64 tag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == nblocks - 1) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (flag_a) sys_store(flag_a, tag);
-      if (flag_b) sys_store(flag_b, tag);
+template <typename T, int VEC>
+__device__ __forceinline__ void gran_store_vec(u64* buf, int64_t elem, vec_t<T, VEC> v, unsigned tag) {
+  const u64 t = (u64)tag << 32;
+  u64* g = buf + elem * Gran<T>::N;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if (Gran<T>::N == 1) {
+      sys_store(g + j, t | (u64)__float_as_uint((float)v[j]));
+    } else {
+      const u64 bits = (u64)__double_as_longlong((double)v[j]);
+      sys_store(g + 2 * j, t | (bits & 0xffffffffull));
+      sys_store(g + 2 * j + 1, t | (bits >> 32));
     }
   }
 }
 
-// Consume: ONE lane polls the (up to two) local flags, then acquires at system scope; the
-// block joins behind it.  Returns false (to every thread) on timeout.
-__device__ __forceinline__ bool await_planes(const u64* flag_a, const u64* flag_b, u64 tag, u64 timeout_ticks) {
-  __shared__ int s_ok;
-  if (threadIdx.x == 0) {
-    bool ok = true;
-    if (flag_a) ok = spin_eq(flag_a, tag, timeout_ticks);
-    if (ok && flag_b) ok = spin_eq(flag_b, tag, timeout_ticks);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_ok = ok ? 1 : 0;
+// false on timeout (the payload never arrived); re-reads until every granule carries `tag`
+template <typename T, int VEC>
+__device__ __forceinline__ bool gran_load_vec(const u64* buf, int64_t elem, unsigned tag, u64 timeout_ticks,
+                                              vec_t<T, VEC>* out) {
+  constexpr int NG = VEC * Gran<T>::N;
+  const u64* g = buf + elem * Gran<T>::N;
+  u64 w[NG];
+  bool all = true;
+#pragma unroll
+  for (int k = 0; k < NG; ++k) { w[k] = sys_load(g + k); all = all && (unsigned)(w[k] >> 32) == tag; }
+  if (!all) {
+    const u64 t0 = wall_clock64();
+    for (;;) {
+      __builtin_amdgcn_s_sleep(1);
+      all = true;
+#pragma unroll
+      for (int k = 0; k < NG; ++k) { w[k] = sys_load(g + k); all = all && (unsigned)(w[k] >> 32) == tag; }
+      if (all) break;
+      if (wall_clock64() - t0 > timeout_ticks) return false;
+    }
   }
-  __syncthreads();
-  return s_ok != 0;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if (Gran<T>::N == 1) (*out)[j] = (T)__uint_as_float((unsigned)w[j]);
+    else (*out)[j] = (T)__longlong_as_double((long long)((w[2 * j + 1] << 32) | (w[2 * j] & 0xffffffffull)));
+  }
+  return true;
 }
 
 // ------------------------------------------------------------------ host side --------------
 struct P2pHost {
   int rank = 0, world = 1;
-  size_t plane_bytes = 0, plane_stride = 0, window_bytes = 0;
+  size_t plane_bytes = 0, plane_stride = 0, window_bytes = 0;   // plane_stride: bytes of one receive buffer (granules)
   char* window = nullptr;                     // own window (hipExtMallocWithFlags, fine-grained)
   char* peer_window[kP2pMaxWorld] = {};       // IPC-mapped peers ([rank] = own)
   bool opened[kP2pMaxWorld] = {};

@@ -1,30 +1,34 @@
 // mfs_p2p.hip -- the peer-to-peer window object of the slab-decomposed CG (see mfs_p2p.h):
 // allocation, HIP-IPC hand-shake, and a collective self-test that moves a real plane
-// payload, flags and an all-reduce through the mapped windows before a solver trusts them.
+// payload and an all-reduce through the mapped windows before a solver trusts them.
 #include "mfs_p2p.h"
 
 namespace mfs {
 
-constexpr u64 kTestHaloTag = 0xFFFFull << 48;
+constexpr unsigned kTestHaloTag = 0x20000000u;
 constexpr unsigned kTestArTag = 0x40000000u;
 
-__device__ __forceinline__ u64 test_pattern(int rank, int round, int side, u64 i) {
-  return 0x9E3779B97F4A7C15ull * (i + 1) + ((u64)(rank + 1) << 40) + ((u64)(round + 1) << 20) + (u64)side;
+__device__ __forceinline__ float test_pattern(int rank, int round, int side, int64_t i) {
+  return (float)((i * 31 + rank * 7 + round * 3 + side) % 8191) - 4095.0f;
 }
 
-// ONE block.  result[0] = 1 ok / 0 failed, result[1] = payload words that did not match,
-// result[2] = timeouts (bit 0 all-reduce, bit 1 halo), result[3] = all-reduce sum as float bits
+// ONE block.  result[0] = 1 ok / 0 failed, result[1] = payload vectors that never arrived or did not
+// match, result[2] = all-reduce timed out, result[3] = all-reduce sum as float bits
 static __global__ void __launch_bounds__(256)
-k_p2p_selftest(P2pDev pd, size_t plane_bytes, int round, unsigned* ticket, unsigned* result) {
+k_p2p_selftest(P2pDev pd, int64_t plane_floats, int round, unsigned* result) {
   const int par = round & 1, tid = threadIdx.x;
-  const u64 nw = plane_bytes / 8;
-  // payload to both neighbours (pattern depends on sender and side), then the flags
+  const int64_t nv = plane_floats / 4;
+  const unsigned htag = kTestHaloTag | (unsigned)(round + 1);
+  // a patterned fp32 plane to both neighbours
   for (int s = 0; s < 2; ++s) {
     if (!pd.send[s][par]) continue;
-    u64* dst = reinterpret_cast<u64*>(pd.send[s][par]);
-    for (u64 i = tid; i < nw; i += blockDim.x) sys_store(dst + i, test_pattern(pd.rank, round, s, i));
+    for (int64_t i = tid; i < nv; i += blockDim.x) {
+      vec_t<float, 4> v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = test_pattern(pd.rank, round, s, 4 * i + j);
+      gran_store_vec<float, 4>(pd.send[s][par], 4 * i, v, htag);
+    }
   }
-  publish_planes(ticket, 1u, pd.send_flag[0][par], pd.send_flag[1][par], kTestHaloTag | (u64)(round + 1));
   // all-reduce
   __shared__ double s_sum;
   __shared__ int s_arok;
@@ -36,17 +40,16 @@ k_p2p_selftest(P2pDev pd, size_t plane_bytes, int round, unsigned* ticket, unsig
   }
   __syncthreads();
   // planes from the neighbours: my low ghost comes from rank-1 (its side-1 send), my high ghost from rank+1
-  const bool have_lo = pd.rank > 0, have_hi = pd.rank < pd.world - 1;
-  const bool halo_ok = await_planes(have_lo ? &pd.self->halo_flag[0][par] : nullptr,
-                                    have_hi ? &pd.self->halo_flag[1][par] : nullptr,
-                                    kTestHaloTag | (u64)(round + 1), pd.timeout_ticks);
   unsigned bad = 0;
-  if (halo_ok) {
-    for (int s = 0; s < 2; ++s) {
-      if (!(s == 0 ? have_lo : have_hi)) continue;
-      const u64* src = reinterpret_cast<const u64*>(pd.recv[s][par]);
-      const int from = s == 0 ? pd.rank - 1 : pd.rank + 1, from_side = s == 0 ? 1 : 0;
-      for (u64 i = tid; i < nw; i += blockDim.x) bad += sys_load(src + i) != test_pattern(from, round, from_side, i);
+  for (int s = 0; s < 2; ++s) {
+    const bool have = s == 0 ? pd.rank > 0 : pd.rank < pd.world - 1;
+    if (!have) continue;
+    const int from = s == 0 ? pd.rank - 1 : pd.rank + 1, from_side = s == 0 ? 1 : 0;
+    for (int64_t i = tid; i < nv; i += blockDim.x) {
+      vec_t<float, 4> v;
+      if (!gran_load_vec<float, 4>(pd.recv[s][par], 4 * i, htag, pd.timeout_ticks, &v)) { ++bad; break; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bad += v[j] != test_pattern(from, round, from_side, 4 * i + j);
     }
   }
   __shared__ unsigned s_bad;
@@ -56,10 +59,10 @@ k_p2p_selftest(P2pDev pd, size_t plane_bytes, int round, unsigned* ticket, unsig
   __syncthreads();
   if (tid == 0) {
     const double want = 1.5 * pd.world * (pd.world + 1) / 2.0 + (double)round * pd.world;
-    const bool ok = halo_ok && s_arok && s_bad == 0 && s_sum == want;
+    const bool ok = s_arok && s_bad == 0 && s_sum == want;
     result[0] = ok ? 1u : 0u;
     result[1] = s_bad;
-    result[2] = (s_arok ? 0u : 1u) | (halo_ok ? 0u : 2u);
+    result[2] = s_arok ? 0u : 1u;
     result[3] = __float_as_uint((float)s_sum);
   }
 }
@@ -70,18 +73,14 @@ static void p2p_fill_dev(P2pHost& p) {
   d.rank = p.rank; d.world = p.world;
   d.self = reinterpret_cast<P2pCtrl*>(p.window);
   for (int r = 0; r < p.world; ++r) d.peer[r] = reinterpret_cast<P2pCtrl*>(p.peer_window[r]);
-  auto buf = [&](char* w, int side, int par) { return w + kP2pCtrlBytes + (size_t)(side * 2 + par) * p.plane_stride; };
+  auto buf = [&](char* w, int side, int par) {
+    return reinterpret_cast<u64*>(w + kP2pCtrlBytes + (size_t)(side * 2 + par) * p.plane_stride);
+  };
   for (int s = 0; s < 2; ++s)
     for (int q = 0; q < 2; ++q) d.recv[s][q] = buf(p.window, s, q);
   for (int q = 0; q < 2; ++q) {
-    if (p.rank > 0) {                      // my plane 1 is the left neighbour's HIGH ghost (side 1)
-      d.send[0][q] = buf(p.peer_window[p.rank - 1], 1, q);
-      d.send_flag[0][q] = &d.peer[p.rank - 1]->halo_flag[1][q];
-    }
-    if (p.rank < p.world - 1) {            // my plane L-2 is the right neighbour's LOW ghost (side 0)
-      d.send[1][q] = buf(p.peer_window[p.rank + 1], 0, q);
-      d.send_flag[1][q] = &d.peer[p.rank + 1]->halo_flag[0][q];
-    }
+    if (p.rank > 0) d.send[0][q] = buf(p.peer_window[p.rank - 1], 1, q);            // my plane 1 = left neighbour's HIGH ghost
+    if (p.rank < p.world - 1) d.send[1][q] = buf(p.peer_window[p.rank + 1], 0, q);  // my plane L-2 = right neighbour's LOW ghost
   }
   const int ms = std::max(1, env_int("MFS_P2P_TIMEOUT_MS", 3000));
   d.timeout_ticks = (u64)ms * 100000ull;   // wall_clock64 ticks at 100 MHz
@@ -102,7 +101,7 @@ int mfs_p2p_create(mfs_p2p** out, int rank, int world, size_t plane_bytes, void*
   mfs_p2p* p = new mfs_p2p();
   p->rank = rank; p->world = world;
   p->plane_bytes = plane_bytes;
-  p->plane_stride = (plane_bytes + 4095) / 4096 * 4096;
+  p->plane_stride = (2 * plane_bytes + 4095) / 4096 * 4096;   // granules: 8 bytes per 32 payload bits
   p->window_bytes = kP2pCtrlBytes + 4 * p->plane_stride;
   void* w = nullptr;
   // memory that peers write while local kernels read must not sit in a non-coherent cache:
@@ -163,10 +162,9 @@ int mfs_p2p_selftest(mfs_p2p* p, int round, mfs_stream stream, int* ok_host, uns
   MFS_REQUIRE(p->connected, "mfs_p2p_connect has not been called");
   MFS_REQUIRE(round >= 0 && round < 1000000, "round");
   hipStream_t st = (hipStream_t)stream;
-  unsigned* ticket = p->local + 16;
   unsigned* result = p->local + 32;
   MFS_HIP_TRY(hipMemsetAsync(result, 0, 16, st));
-  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(256), 0, st, p->dev, p->plane_bytes, round, ticket, result);
+  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(256), 0, st, p->dev, (int64_t)(p->plane_bytes / 4), round, result);
   MFS_LAUNCH_CHECK();
   unsigned host[4] = {0, 0, 0, 0};
   MFS_HIP_TRY(hipMemcpyAsync(host, result, sizeof(host), hipMemcpyDeviceToHost, st));

@@ -546,18 +546,17 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
   T* d_prev = (T*)((j & 1) ? h->c.d : h->d2);
   const SlabEdge e = slab_edges(L, p->rank, p->world);
   const int64_t plane_elems = (int64_t)h->Ny * h->Nz;
-  const u64 halo_tag = ((u64)p->epoch << 32) | (u64)(j + 1);
-  unsigned* ticket = p->local;
+  const unsigned halo_tag = 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)((j + 1) & 0xfffff);
   int e_;
   // 1. edge planes of d_j: local + into the neighbours' windows
   if (e.np > 0) {
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->cus, (plane_elems / VEC + kBlock - 1) / kBlock));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(4 * h->cus, (plane_elems / VEC + kBlock - 1) / kBlock));
     if (j == 0)
       hipLaunchKernelGGL((k_slab_edge_d<T, VEC, true>), dim3(grid), dim3(kBlock), 0, st, (const T*)nullptr, (const T*)d_cur,
-                         (T*)nullptr, plane_elems, e, h->c.scal, p->dev, par, halo_tag, ticket);
+                         (T*)nullptr, plane_elems, e, h->c.scal, p->dev, par, halo_tag);
     else
       hipLaunchKernelGGL((k_slab_edge_d<T, VEC, false>), dim3(grid), dim3(kBlock), 0, st, (const T*)h->c.r, (const T*)d_prev,
-                         d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag, ticket);
+                         d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag);
     MFS_LAUNCH_CHECK();
   }
   // 2. planes that touch no ghost, while the edge planes travel
@@ -585,7 +584,7 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
   h->c.n_part_dq = n_part;
   // 4. d.q over all ranks   5. x, r update   6. r.r over all ranks + bookkeeping (closes the iteration)
   if ((e_ = slab_allreduce<0>(h, h->c.part_dq, n_part, 2 * j + 1, st))) return e_;
-  if ((e_ = core_update_xr(h->c, false, st, 0, d_cur))) return e_;
+  if ((e_ = core_update_xr(h->c, false, st, 0, d_cur, plane_elems, plane_elems * (L - 2)))) return e_;   // owned planes only
   if ((e_ = slab_allreduce<1>(h, h->c.part_rr, h->c.n_part_rr, 2 * j + 2, st))) return e_;
   ++h->c.iter_enq;
   return MFS_OK;

@@ -3,11 +3,11 @@
 // ONE stream, no host synchronisation and no library collective inside the loop:
 //
 //   k_slab_edge_d       d_j = r + beta d_{j-1} on the two edge planes {1, L-2}; each plane
-//                       is stored locally AND into the neighbour's window, then flagged
+//                       is stored locally AND, as tagged granules, into the neighbour's window
 //   <stencil launch>    planes [2, L-2): the single-GPU LDS march with the direction update
 //                       folded in (mfs_pcg_apply.h) -- runs while the edge planes travel
 //   k_slab_edge_apply   q on the two edge planes, ghost plane read from the own window
-//                       once the neighbour's flag has arrived; d.q partials
+//                       (granules re-read until they carry this iteration's tag); d.q partials
 //   k_slab_allreduce    local partials -> every rank's window -> sum in rank order -> d.q
 //   k_update_xr         alpha, x += alpha d, r -= alpha q, r.r partials   (mfs_cg_core.h)
 //   k_slab_allreduce    r.r, then the convergence test / history / beta bookkeeping
@@ -52,14 +52,14 @@ __device__ __forceinline__ void slab_fail(double* scal, int code) {
 template <typename T, int VEC, bool FIRST>
 __global__ void __launch_bounds__(kBlock)
 k_slab_edge_d(const T* __restrict__ r, const T* __restrict__ d_old, T* __restrict__ d_new, int64_t plane_elems,
-              SlabEdge e, const double* __restrict__ scal, P2pDev pd, int par, u64 tag, unsigned* ticket) {
+              SlabEdge e, const double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
   if (scal[S_DONE] != 0.0) return;
   const double beta = FIRST ? 0.0 : scal[S_BETA];
   const int64_t nv = plane_elems / VEC, stride = (int64_t)gridDim.x * blockDim.x;
   for (int k = 0; k < e.np; ++k) {
     const int64_t p0 = (int64_t)e.plane[k] * plane_elems;
-    T* const left = e.to_left[k] ? reinterpret_cast<T*>(pd.send[0][par]) : nullptr;
-    T* const right = e.to_right[k] ? reinterpret_cast<T*>(pd.send[1][par]) : nullptr;
+    u64* const left = e.to_left[k] ? pd.send[0][par] : nullptr;
+    u64* const right = e.to_right[k] ? pd.send[1][par] : nullptr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
       vec_t<T, VEC> dv = vload<T, VEC>(d_old + p0 + i * VEC);
       if (!FIRST) {
@@ -68,35 +68,30 @@ k_slab_edge_d(const T* __restrict__ r, const T* __restrict__ d_old, T* __restric
         for (int j = 0; j < VEC; ++j) dv[j] = (T)((double)rv[j] + beta * (double)dv[j]);
         vstore<T, VEC>(d_new + p0 + i * VEC, dv);
       }
-      if (left) vstore_sys<T, VEC>(left + i * VEC, dv);
-      if (right) vstore_sys<T, VEC>(right + i * VEC, dv);
+      if (left) gran_store_vec<T, VEC>(left, i * VEC, dv, tag);
+      if (right) gran_store_vec<T, VEC>(right, i * VEC, dv, tag);
     }
   }
-  publish_planes(ticket, gridDim.x, pd.send_flag[0][par], pd.send_flag[1][par], tag);
 }
 
 // q = A d on the edge planes.  Direct loads (two planes of work: the march's register reuse has
-// nothing to amortise); the x-1 / x+1 operand of a plane next to a neighbour comes from the window.
+// nothing to amortise); the x-1 / x+1 operand of a plane next to a neighbour comes from the window,
+// re-read until its granules carry this iteration's tag.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kApplyBlock)
 k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag, const T* __restrict__ cx,
                   const T* __restrict__ cy, const T* __restrict__ cz, int L, int Ny, int Nz, SlabEdge e,
-                  double* __restrict__ partial, double* __restrict__ scal, P2pDev pd, int par, u64 tag) {
+                  double* __restrict__ partial, double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
   if (scal[S_DONE] != 0.0) return;
   const bool has_left = pd.rank > 0, has_right = pd.rank < pd.world - 1;
-  const bool ok = await_planes(has_left ? &pd.self->halo_flag[0][par] : nullptr,
-                               has_right ? &pd.self->halo_flag[1][par] : nullptr, tag, pd.timeout_ticks);
-  if (!ok) {
-    if (threadIdx.x == 0) { slab_fail(scal, 2); partial[blockIdx.x] = 0.0; }
-    return;
-  }
-  const T* const ghost_lo = reinterpret_cast<const T*>(pd.recv[0][par]);
-  const T* const ghost_hi = reinterpret_cast<const T*>(pd.recv[1][par]);
+  const u64* const ghost_lo = pd.recv[0][par];
+  const u64* const ghost_hi = pd.recv[1][par];
   const int nzv = Nz / VEC;
   const int64_t ipp = (int64_t)(Ny - 2) * nzv;
   const int64_t sx = (int64_t)Ny * Nz, sy = Nz;
   const int64_t items = (int64_t)e.np * ipp, stride = (int64_t)gridDim.x * kApplyBlock;
   double acc = 0.0;
+  bool lost = false;
   for (int64_t it = (int64_t)blockIdx.x * kApplyBlock + threadIdx.x; it < items; it += stride) {
     const int px = (int)(it / ipp);
     const int rem = (int)(it - (int64_t)px * ipp);
@@ -106,8 +101,12 @@ k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     const int64_t base = (int64_t)xx * sx + in_plane;
     const bool first = zv == 0, last = zv == nzv - 1;
     const auto vc = vload<T, VEC>(v + base);
-    const auto vxm = (xx == 1 && has_left) ? vload_sys<T, VEC>(ghost_lo + in_plane) : vload<T, VEC>(v + base - sx);
-    const auto vxp = (xx == L - 2 && has_right) ? vload_sys<T, VEC>(ghost_hi + in_plane) : vload<T, VEC>(v + base + sx);
+    vec_t<T, VEC> vxm, vxp;
+    if (xx == 1 && has_left) lost = lost || !gran_load_vec<T, VEC>(ghost_lo, in_plane, tag, pd.timeout_ticks, &vxm);
+    else vxm = vload<T, VEC>(v + base - sx);
+    if (xx == L - 2 && has_right) lost = lost || !gran_load_vec<T, VEC>(ghost_hi, in_plane, tag, pd.timeout_ticks, &vxp);
+    else vxp = vload<T, VEC>(v + base + sx);
+    if (lost) break;
     const double zl = first ? 0.0 : (double)v[base - 1];
     const double zr = last ? 0.0 : (double)v[base + VEC];
     const double czr = last ? 0.0 : (double)cz[base + VEC];
@@ -116,6 +115,7 @@ k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restr
                         vload<T, VEC>(cy + base + sy), vload<T, VEC>(cy + base), vload<T, VEC>(cz + base), zl, zr, czr,
                         first, last, true, acc);
   }
+  if (lost) slab_fail(scal, 2);
   const double tot = block_sum<kApplyBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }

@@ -17,8 +17,8 @@ from . import _lib, tensors as T
 
 class P2PWindow:
     """COLLECTIVE constructor: every rank of `group` creates its window, the IPC handles are
-    all-gathered, the peers' windows are mapped and a self-test moves real plane payloads,
-    flags and an all-reduce through them.  `self.ok` is True only if EVERY rank passed;
+    all-gathered, the peers' windows are mapped and a self-test moves real plane payloads
+    and an all-reduce through them.  `self.ok` is True only if EVERY rank passed;
     the caller falls back to the RCCL loop (mfs.dist.SlabCG mode "rccl") otherwise."""
 
     def __init__(self, dist, plane_bytes, device, group=None, rounds=3):
