@@ -30,6 +30,7 @@
 #include <algorithm>
 
 #include "mfs_common.h"
+#include "mfs_p2p.h"
 
 namespace mfs {
 
@@ -100,6 +101,72 @@ __device__ __forceinline__ double block_total_of(const double* __restrict__ part
   return s_tot;
 }
 
+// In-launch reduction tail.  Every block calls it with its partial sum (thread 0's `my_val`); it
+// returns true -- to every thread -- in exactly ONE block, the last to arrive, where *total is the sum
+// of partial[0..count) in block_total_of's order (so the value is the one a following kernel would
+// compute).  Hand-off: write-through (sc1) partial store, drained, then a relaxed agent-scope ticket;
+// the block whose ticket is the last reads every partial with sc1 loads behind a workgroup barrier.
+__device__ __forceinline__ bool last_block_total(double* __restrict__ partial, int my_slot, double my_val, int count,
+                                                 unsigned* ticket, unsigned nblocks, double* total) {
+  __shared__ int s_last;
+  __shared__ double s_total;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(partial + my_slot, my_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == nblocks - 1;
+    if (t == nblocks - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+  }
+  __syncthreads();
+  if (!s_last) return false;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock)
+    acc += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double t = block_sum<kBlock>(acc);
+  if (threadIdx.x == 0) s_total = t;
+  __syncthreads();
+  *total = s_total;
+  return true;
+}
+
+// the bookkeeping that closes an iteration (ONE thread): convergence test (:218), history, iteration
+// count, delta ring, beta (:220)
+__device__ __forceinline__ void cg_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
+                                        double dq, double rr) {
+  const double delta = scal[S_RING + par];
+  const int64_t it = (int64_t)scal[S_ITERS];
+  if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+  scal[S_ITERS] = (double)(it + 1);
+  scal[S_RING + (par ^ 1)] = rr;
+  scal[S_RR] = rr;
+  scal[S_DELTA] = delta;
+  scal[S_LASTRR] = rr;
+  scal[S_ALPHA] = delta / dq;
+  if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rr / delta;
+}
+
+// one wave: this rank's value -> every rank's window -> the world's total in rank order (lane 0); see mfs_p2p.h
+__device__ __forceinline__ double slab_allreduce_wave(const P2pDev& pd, int ring, unsigned tag, double v, bool* ok) {
+  ar_send(pd, ring, tag, v, threadIdx.x);
+  return ar_recv(pd, ring, tag, threadIdx.x, ok);
+}
+
+__device__ __forceinline__ void slab_fail(double* scal, int code) {
+  // a peer did not answer: raise the error word and stop the solve (every later kernel returns at its top)
+  __hip_atomic_store(scal + S_ERR, (double)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(scal + S_DONE, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what the LAST block of k_update_xr does after the r.r partials are complete
+struct XrTail {
+  int kind;                 // 0 nothing; 1 bookkeeping (one GPU); 2 all-reduce over the windows, then bookkeeping (slab loop)
+  double* hist;
+  int64_t hist_cap;
+  unsigned* ticket;
+  int ring;
+  unsigned tag;
+};
+
 // alpha = delta / dq ; x += alpha d ; r -= alpha q ; partial sum r^2   (:211-216)
 // NTX: x is touched once per iteration and by no other kernel -> stream it past the
 // caches (nontemporal load + store) so that d, r, q keep their Infinity-Cache lines.
@@ -109,7 +176,7 @@ template <typename T, int VEC, bool NTX, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
             double* __restrict__ scal, double* __restrict__ partial, int rev, int par,
-            const double* __restrict__ part_dq, int npart) {
+            const double* __restrict__ part_dq, int npart, XrTail tail, P2pDev pd) {
   if (scal[S_DONE] != 0.0) return;
   // d.q: folded reduction of the apply's partials (npart > 0) or the all-reduced scalar
   const double dq = npart > 0 ? block_total_of(part_dq, npart) : scal[S_DQ];
@@ -146,7 +213,20 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
   }, rev != 0);
   if (MODE != 2) {
     const double tot = block_sum<kBlock>(acc);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    if (tail.kind == 0) {
+      if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+      return;
+    }
+    // the iteration is closed by the last block to get here instead of by a kernel of its own
+    double rr;
+    if (!last_block_total(partial, blockIdx.x, tot, gridDim.x, tail.ticket, gridDim.x, &rr)) return;
+    if (threadIdx.x >= kWave) return;
+    if (tail.kind == 2) {
+      bool ok;
+      rr = slab_allreduce_wave(pd, tail.ring, tail.tag, rr, &ok);
+      if (!ok) { if (threadIdx.x == 0) slab_fail(scal, 1); return; }
+    }
+    if (threadIdx.x == 0) cg_book(scal, tail.hist, tail.hist_cap, par, dq, rr);
   }
 }
 
@@ -216,18 +296,7 @@ k_cg_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap
           const double* __restrict__ part_rr, int npart) {
   if (scal[S_DONE] != 0.0) return;
   const double rr = block_total_of(part_rr, npart);
-  if (threadIdx.x == 0) {
-    const double delta = scal[S_RING + par], dq = scal[S_DQ];
-    const int64_t it = (int64_t)scal[S_ITERS];
-    if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
-    scal[S_ITERS] = (double)(it + 1);
-    scal[S_RING + (par ^ 1)] = rr;
-    scal[S_RR] = rr;
-    scal[S_DELTA] = delta;
-    scal[S_LASTRR] = rr;
-    scal[S_ALPHA] = delta / dq;
-    if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rr / delta;
-  }
+  if (threadIdx.x == 0) cg_book(scal, hist, hist_cap, par, scal[S_DQ], rr);
 }
 
 // x *= 0.0 (:198) -- a multiply, not a memset, so NaN/inf survive as in the reference.
@@ -275,6 +344,7 @@ struct CgCore {
   int64_t n = 0;
   size_t elt = 8;
   double *scal = nullptr, *hist = nullptr, *part_dq = nullptr, *part_rr = nullptr;
+  unsigned* tickets = nullptr;   // arrival counters of the in-launch reduction tails (zero between launches)
   void *b = nullptr, *x = nullptr, *d = nullptr, *r = nullptr, *q = nullptr;
   int n_part_dq = 0, n_part_rr = 0;
   int grid_vec = 2048, cus = 256;
@@ -290,7 +360,7 @@ static inline size_t core_ws_bytes() {
 
 // carve scalars / history / partials out of the head of the workspace; returns the first free byte
 static inline char* core_carve(CgCore& c, char* p) {
-  c.scal = (double*)p; p += 256;
+  c.scal = (double*)p; c.tickets = (unsigned*)(p + 192); p += 256;   // 16 doubles, then the tickets
   c.hist = (double*)p; p += align_up((size_t)kHistCap * 8, 256);
   c.part_dq = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
   c.part_rr = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
@@ -352,7 +422,7 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
 #define MFS_XR(TT, VV, NN, MM) \
   hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x + off, (const TT*)dsrc + off, \
                      (TT*)c.r + off, (const TT*)c.q + off, cnt, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), \
-                     c.part_dq, fold ? c.n_part_dq : 0)
+                     c.part_dq, fold ? c.n_part_dq : 0, tl, pdv)
 #define MFS_XR_MODE(MM)                                                                                              \
   if (c.dt == MFS_F32) {                                                                                             \
     if (!vec) MFS_XR(float, 1, false, MM); else if (ntx) MFS_XR(float, 4, true, MM); else MFS_XR(float, 4, false, MM); \
@@ -361,9 +431,15 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
   }
 // mode 0: x and r together; 1: r only (+ r.r partials); 2: x only.  [off, off + cnt) restricts the
 // update to a sub-range of the DOFs (the slab loop skips its ghost planes; off a multiple of 16 bytes)
+// tail / pd: let the last block close the iteration (XrTail); default none.
 static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode = 0, const void* d_override = nullptr,
-                                 int64_t off = 0, int64_t cnt = -1) {
+                                 int64_t off = 0, int64_t cnt = -1, const XrTail* tail = nullptr,
+                                 const P2pDev* pd = nullptr) {
   MFS_REQUIRE(c.x, "engine not bound");
+  MFS_REQUIRE(!tail || mode == 0, "an iteration-closing tail needs the combined x/r update");
+  XrTail tl = tail ? *tail : XrTail{};
+  if (tail) tl.ticket = c.tickets;
+  const P2pDev pdv = pd ? *pd : P2pDev{};
   const void* dsrc = d_override ? d_override : c.d;
   if (cnt < 0) cnt = c.n - off;
   MFS_REQUIRE(off >= 0 && cnt >= 0 && off + cnt <= c.n, "update range");
@@ -391,6 +467,16 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st) {
   }
   MFS_LAUNCH_CHECK();
   ++c.iter_enq;      // the d update closes an iteration
+  return MFS_OK;
+}
+
+// update_xr whose last block also closes the iteration (kind 1: bookkeeping; 2: all-reduce + bookkeeping)
+static inline int core_update_xr_close(CgCore& c, bool fold, hipStream_t st, const void* d_src, int kind,
+                                       int64_t off = 0, int64_t cnt = -1, const P2pDev* pd = nullptr, int ring = 0,
+                                       unsigned tag = 0) {
+  XrTail tl{kind, c.hist, kHistCap, nullptr, ring, tag};
+  if (int e = core_update_xr(c, fold, st, 0, d_src, off, cnt, &tl, pd)) return e;
+  ++c.iter_enq;
   return MFS_OK;
 }
 

@@ -448,8 +448,8 @@ int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
     return core_update_d(h->c, true, st);
   }
   const int64_t j = h->c.iter_enq;
-  if ((e = core_update_xr(h->c, true, st, 0, (j & 1) ? h->d2 : h->c.d))) return e;
-  return core_book(h->c, st);
+  // the last block of the update closes the iteration (convergence test, history, beta): 2 launches per iteration
+  return core_update_xr_close(h->c, true, st, (j & 1) ? h->d2 : h->c.d, 1);
 }
 
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
@@ -527,15 +527,6 @@ static unsigned slab_ar_tag(const mfs_p2p* p, int64_t episode) {
   return 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)(episode & 0xfffff);
 }
 
-template <int WHICH>
-static int slab_allreduce(mfs_pcg3d* h, const double* partial, int count, int64_t episode, hipStream_t st) {
-  hipLaunchKernelGGL((k_slab_allreduce<WHICH>), dim3(1), dim3(kBlock), 0, st, partial, count, h->c.scal, h->c.hist,
-                     kHistCap, (int)(h->c.iter_enq & 1), h->p2p->dev, (int)(episode & (kArRing - 1)),
-                     slab_ar_tag(h->p2p, episode));
-  MFS_LAUNCH_CHECK();
-  return MFS_OK;
-}
-
 template <typename T>
 static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
   constexpr int VEC = VecOf<T>::N;
@@ -577,17 +568,15 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (items + kApplyBlock - 1) / kApplyBlock));
     hipLaunchKernelGGL((k_slab_edge_apply<T, VEC>), dim3(grid), dim3(kApplyBlock), 0, st, (const T*)d_cur, (T*)h->c.q,
                        (const T*)h->diag, (const T*)h->cx, (const T*)h->cy, (const T*)h->cz, L, h->Ny, h->Nz, e,
-                       h->c.part_dq + n_part, h->c.scal, p->dev, par, halo_tag);
+                       h->c.part_dq, n_part, h->c.scal, p->dev, par, halo_tag, h->c.tickets + 1,
+                       (int)((2 * j + 1) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 1));
     MFS_LAUNCH_CHECK();
     n_part += grid;
   }
   h->c.n_part_dq = n_part;
-  // 4. d.q over all ranks   5. x, r update   6. r.r over all ranks + bookkeeping (closes the iteration)
-  if ((e_ = slab_allreduce<0>(h, h->c.part_dq, n_part, 2 * j + 1, st))) return e_;
-  if ((e_ = core_update_xr(h->c, false, st, 0, d_cur, plane_elems, plane_elems * (L - 2)))) return e_;   // owned planes only
-  if ((e_ = slab_allreduce<1>(h, h->c.part_rr, h->c.n_part_rr, 2 * j + 2, st))) return e_;
-  ++h->c.iter_enq;
-  return MFS_OK;
+  // 4. x, r update; its last block: r.r over all ranks + bookkeeping (closes the iteration)
+  return core_update_xr_close(h->c, false, st, d_cur, 2, plane_elems, plane_elems * (L - 2), &p->dev,
+                              (int)((2 * j + 2) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 2));
 }
 
 extern "C" {
@@ -611,7 +600,9 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   int grid = 0;
   if (int e = apply_dispatch(h, h->c.x, h->c.q, 1, h->Nx - 1, h->c.part_dq, 0, st, &grid)) return e;  // q = A x (:201)
   if (int e = core_begin_post(h->c, st, false)) return e;             // d = r = b - q, partials of r.r
-  if (int e = slab_allreduce<2>(h, h->c.part_rr, h->c.n_part_rr, 0, st)) return e;
+  hipLaunchKernelGGL(k_slab_allreduce_rr, dim3(1), dim3(kBlock), 0, st, h->c.part_rr, h->c.n_part_rr, h->c.scal,
+                     h->p2p->dev, 0, slab_ar_tag(h->p2p, 0));
+  MFS_LAUNCH_CHECK();
   return core_begin_finish(h->c, st);
 }
 

@@ -7,10 +7,13 @@
 //   <stencil launch>    planes [2, L-2): the single-GPU LDS march with the direction update
 //                       folded in (mfs_pcg_apply.h) -- runs while the edge planes travel
 //   k_slab_edge_apply   q on the two edge planes, ghost plane read from the own window
-//                       (granules re-read until they carry this iteration's tag); d.q partials
-//   k_slab_allreduce    local partials -> every rank's window -> sum in rank order -> d.q
-//   k_update_xr         alpha, x += alpha d, r -= alpha q, r.r partials   (mfs_cg_core.h)
-//   k_slab_allreduce    r.r, then the convergence test / history / beta bookkeeping
+//                       (granules re-read until they carry this iteration's tag); its LAST block
+//                       adds up the d.q partials, sends the sum into every rank's window and
+//                       adds the world's slots in rank order -> d.q
+//   k_update_xr         alpha, x += alpha d, r -= alpha q (mfs_cg_core.h); its LAST block does the
+//                       same for r.r, then the convergence test / history / beta bookkeeping
+//
+// Four launches per iteration (one GPU: two).
 //
 // The arithmetic of every cell is the single-GPU kernels' (same stencil_vec, same update
 // expressions), so a slab solve differs from the single-domain one only in the order in
@@ -39,12 +42,6 @@ static inline SlabEdge slab_edges(int L, int rank, int world) {
   e.to_left[0] = left; e.to_right[0] = (hi == lo) && right;
   e.to_left[1] = 0;    e.to_right[1] = (hi > lo) && right;
   return e;
-}
-
-__device__ __forceinline__ void slab_fail(double* scal, int code) {
-  // a peer did not answer: raise the error word and stop the solve (every later kernel returns at its top)
-  __hip_atomic_store(scal + S_ERR, (double)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(scal + S_DONE, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // d_new = r + beta d_old on the edge planes (exactly k_update_d's expression); FIRST: iteration 0,
@@ -81,7 +78,8 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(kApplyBlock)
 k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag, const T* __restrict__ cx,
                   const T* __restrict__ cy, const T* __restrict__ cz, int L, int Ny, int Nz, SlabEdge e,
-                  double* __restrict__ partial, double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
+                  double* __restrict__ partial_all, int n_before, double* __restrict__ scal, P2pDev pd, int par,
+                  unsigned tag, unsigned* ticket, int ar_ring, unsigned ar_tag) {
   if (scal[S_DONE] != 0.0) return;
   const bool has_left = pd.rank > 0, has_right = pd.rank < pd.world - 1;
   const u64* const ghost_lo = pd.recv[0][par];
@@ -117,17 +115,24 @@ k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restr
   }
   if (lost) slab_fail(scal, 2);
   const double tot = block_sum<kApplyBlock>(acc);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  // the last block to get here adds up ALL of this iteration's d.q partials (the interior launch's
+  // [0, n_before), then this launch's), sends the sum to every rank and takes the world's total
+  double dq;
+  if (!last_block_total(partial_all, n_before + blockIdx.x, tot, n_before + gridDim.x, ticket, gridDim.x, &dq)) return;
+  if (threadIdx.x >= kWave) return;
+  bool ok;
+  dq = slab_allreduce_wave(pd, ar_ring, ar_tag, dq, &ok);
+  if (threadIdx.x != 0) return;
+  if (!ok) { slab_fail(scal, 1); return; }
+  scal[S_DQ] = dq;
 }
 
-// ONE block: this rank's partial sums -> every rank's window -> the world's total in rank order.
-// WHICH 0: d.q -> scal[S_DQ].  1: r.r, then the bookkeeping of k_cg_book (convergence test
-// PressureCGSolver3D.py:218, history, iteration count, delta ring, beta :220).  2: the r.r of `begin`.
-template <int WHICH>
-__global__ void __launch_bounds__(kBlock)
-k_slab_allreduce(const double* __restrict__ partial, int count, double* __restrict__ scal, double* __restrict__ hist,
-                 int64_t hist_cap, int par, P2pDev pd, int ring, unsigned tag) {
-  if (WHICH != 2 && scal[S_DONE] != 0.0) return;
+// ONE block: this rank's partial sums -> every rank's window -> the world's total in rank order ->
+// scal[S_RR].  Used by `begin` (delta0); inside the loop the reductions ride in the last block of
+// k_slab_edge_apply (d.q) and of k_update_xr (r.r + bookkeeping).
+static __global__ void __launch_bounds__(kBlock)
+k_slab_allreduce_rr(const double* __restrict__ partial, int count, double* __restrict__ scal, P2pDev pd, int ring,
+                    unsigned tag) {
   double acc = 0.0;
   for (int i = threadIdx.x; i < count; i += kBlock) acc += partial[i];
   const double loc = block_sum<kBlock>(acc);          // thread 0
@@ -135,27 +140,11 @@ k_slab_allreduce(const double* __restrict__ partial, int count, double* __restri
   if (threadIdx.x == 0) s_loc = loc;
   __syncthreads();
   if (threadIdx.x >= kWave) return;
-  ar_send(pd, ring, tag, s_loc, threadIdx.x);
   bool ok;
-  const double tot = ar_recv(pd, ring, tag, threadIdx.x, &ok);
+  const double tot = slab_allreduce_wave(pd, ring, tag, s_loc, &ok);
   if (threadIdx.x != 0) return;
   if (!ok) { slab_fail(scal, 1); return; }
-  if (WHICH == 0) {
-    scal[S_DQ] = tot;
-  } else if (WHICH == 2) {
-    scal[S_RR] = tot;
-  } else {
-    const double rr = tot, delta = scal[S_RING + par], dq = scal[S_DQ];
-    const int64_t it = (int64_t)scal[S_ITERS];
-    if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
-    scal[S_ITERS] = (double)(it + 1);
-    scal[S_RING + (par ^ 1)] = rr;
-    scal[S_RR] = rr;
-    scal[S_DELTA] = delta;
-    scal[S_LASTRR] = rr;
-    scal[S_ALPHA] = delta / dq;
-    if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rr / delta;
-  }
+  scal[S_RR] = tot;
 }
 
 }  // namespace mfs
