@@ -146,13 +146,46 @@ class SlabCG:
                 self._allreduce(_lib.S_RR)
             ops.phase_update_d()
 
+    def solve(self, tol, max_iter, check_every=32):
+        """begin + iterate until the device-resident `done` flag or max_iter; returns (converged, iterations).
+        COLLECTIVE.  The scalars every rank tests are bit-identical, so all ranks leave the loop together."""
+        if self.window is not None:
+            return self.ops.slab_solve(tol, max_iter, check_every)
+        if not self.multi:
+            return self.ops.solve(tol, max_iter, check_every)
+        self.begin(tol)
+        st = self.ops.poll()
+        enq = 0
+        while not st["done"] and enq < max_iter:
+            n = min(int(check_every), int(max_iter) - enq)
+            self.iterate(n)
+            enq += n
+            st = self.ops.poll()
+        return bool(st["done"]), int(st["iterations"])
+
     def exchange(self, t):
         """one-off halo exchange of another local field (e.g. x before a velocity update)."""
         if self.dist is None or self.part.world == 1:
             return
-        saved, self.d = self.d, t
-        try:
-            for w in self._halo_start():
-                w.wait()
-        finally:
-            self.d = saved
+        dist, p, L = self.dist, self.part, self.L
+        staged = getattr(t, "is_cuda", False) and dist.get_backend(self.group) != "nccl"
+        if staged:
+            # only RCCL moves device memory; any other backend (gloo in the tests) gets host copies of the
+            # four planes involved.  The copy to the host waits for the kernels that produced them.
+            src = {k: t[k].cpu() for k in (0, 1, L - 2, L - 1)}
+        else:
+            src = t
+        ops = []
+        if p.left is not None:
+            ops.append(dist.P2POp(dist.isend, src[1], p.left, self.group))
+            ops.append(dist.P2POp(dist.irecv, src[0], p.left, self.group))
+        if p.right is not None:
+            ops.append(dist.P2POp(dist.isend, src[L - 2], p.right, self.group))
+            ops.append(dist.P2POp(dist.irecv, src[L - 1], p.right, self.group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        if staged:
+            if p.left is not None:
+                t[0].copy_(src[0])
+            if p.right is not None:
+                t[L - 1].copy_(src[L - 1])

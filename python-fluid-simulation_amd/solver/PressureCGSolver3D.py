@@ -127,3 +127,85 @@ class PressureCGSolver3D:
                 raise ValueError("Failed to converge!")
             # self.x : -pressure * dt / rho / cell_vol
             apply_pressure(g, self.cell_size, vx, vy, vz, self.x, wx, wy, wz, sv, lphi)
+
+
+class SlabPressureCGSolver3D(PressureCGSolver3D):
+    """One rank of a multi-GPU `PressureCGSolver3D` (extension: the reference is single-GPU).
+
+    The GLOBAL grid `gres` is cut into contiguous x-slabs (`mfs.dist.SlabPartition`: array axis 0,
+    the slowest-varying one); one process per GPU.  Every array handed to this object is the rank's
+    LOCAL slab including one ghost / boundary plane on each side:
+
+        cell arrays   planes [lo, hi)        of the global arrays, (lo, hi) = self.part.local_range
+        x-face arrays planes [lo, hi + 1)    (vx, wx);  vy / vz / wy / wz: planes [lo, hi)
+        doubled grid  planes [2 lo, 2 hi + 1)  (sphi, sv)
+
+    `buf` is a `CGSolverBuffer(self.local_gres(gres, world, rank))`.  `solve` has the reference's
+    signature and semantics on the global problem: same RHS, same CG iterates up to the summation
+    order of the two dot products, `ValueError("Failed to converge!")` after prod(global gres)
+    iterations, velocities updated in place on the faces this rank owns (local x-faces 1 .. L-1 and
+    the y/z faces of local planes 1 .. L-1; the shared faces are computed identically by both
+    neighbours).  Collective: every rank calls `solve` in step.
+
+    transport: "p2p" = xGMI stores from the solver's kernels into HIP-IPC windows (mfs/p2p.py),
+    "rccl" = torch.distributed collectives per iteration, "auto" = p2p when its self-test passes
+    on every rank, else rccl."""
+
+    @staticmethod
+    def local_gres(gres, world, rank):
+        from mfs.dist import SlabPartition
+        g = T.as_gres(gres)
+        return (SlabPartition(g[0], world, rank).local_planes, g[1], g[2])
+
+    def __init__(self, buf, gres, bound_size, dist, group=None, transport="auto", check_every=32):
+        from mfs.dist import SlabCG, SlabPartition
+        from mfs.p2p import P2PWindow
+        gg = T.as_gres(gres)
+        self.global_gres = gg
+        self.dist, self.group = dist, group
+        self.part = SlabPartition(gg[0], dist.get_world_size(group), dist.get_rank(group))
+        lg = (self.part.local_planes, gg[1], gg[2])
+        if tuple(buf.b.shape) != lg:
+            raise ValueError(f"buf must be a CGSolverBuffer of this rank's slab {lg} (see local_gres)")
+        super().__init__(buf, lg, bound_size, check_every)
+        # cell size and iteration cap are the GLOBAL problem's (reference :176, :190)
+        self.cell_size = np.array(T.as_f64_list(bound_size, 3)) / np.array(gg, dtype=np.float64)
+        self.max_iter = int(np.prod(gg))
+        if transport not in ("auto", "p2p", "rccl"):
+            raise ValueError("transport must be auto, p2p or rccl")
+        self.window = None
+        if transport != "rccl":
+            self.window = P2PWindow(dist, lg[1] * lg[2] * buf.b.element_size(), buf.b.device, group)
+            if not self.window.ok:
+                why, self.window = self.window.why, None
+                if transport == "p2p":
+                    raise _lib.MfsError(f"peer-to-peer transport unavailable: {why}")
+        self._cg = SlabCG(self._engine, self.part, buf.d, dist, group, window=self.window, force_multi=True)
+        self.transport = self._cg.mode
+
+    def solve(self, vx, vy, vz, sphi, sv, lphi, wx=None, wy=None, wz=None, tol=1e-3):
+        g = self._g
+        if wx is None or wy is None or wz is None:
+            compute_solid_frac(g, sphi, self.wx, self.wy, self.wz)
+            wx, wy, wz = self.wx, self.wy, self.wz
+        eng = self._engine
+        with torch.cuda.device(self.x.device):
+            initialize_solver(self.cell_size, g, vx, vy, vz, sphi, sv, lphi, self.buf.b, wx, wy, wz)
+            self.buf.b[0].zero_()         # ghost / boundary planes carry no equation on this rank
+            self.buf.b[-1].zero_()
+            eng.setup(lphi, wx, wy, wz)
+            eng.bind(self.buf.b, self.x, self.buf.d, self.buf.r, self.buf.q)
+            ok, self.iterations = self._cg.solve(tol, self.max_iter, self.check_every)
+            st = eng.poll()
+            self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
+            if not ok:
+                raise ValueError("Failed to converge!")
+            self._cg.exchange(self.x)     # the neighbours' edge planes of the pressure, for the faces next to them
+            apply_pressure(g, self.cell_size, vx, vy, vz, self.x, wx, wy, wz, sv, lphi)
+
+    def close(self):
+        """COLLECTIVE: release the peer-to-peer window (if any)."""
+        w, self.window = self.window, None
+        if w is not None:
+            self._engine.attach_p2p(None)
+            w.close()

@@ -19,6 +19,28 @@ from mfs.p2p import P2PWindow  # noqa: E402
 from mfs.pcg import PcgEngine  # noqa: E402
 
 
+def solver_mode(rank, world, path, out, dtname, dev):
+    """The drop-in class: SlabPressureCGSolver3D.solve on this rank's slab of the golden scene."""
+    from solver.CGSolverBuffer import CGSolverBuffer
+    from solver.PressureCGSolver3D import SlabPressureCGSolver3D
+    with np.load(path, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    gres = tuple(int(v) for v in g["gres"])
+    lg = SlabPressureCGSolver3D.local_gres(gres, world, rank)
+    buf = CGSolverBuffer(lg, precision={"f64": "fp64", "f32": "fp32"}[dtname], device=dev)
+    s = SlabPressureCGSolver3D(buf, gres, g["bound_size"], dist, transport=os.environ.get("P2P_TEST_TRANSPORT", "p2p"))
+    lo, hi = s.part.local_range
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    vx, vy, vz = T(g["in_vx"][lo:hi + 1]), T(g["in_vy"][lo:hi]), T(g["in_vz"][lo:hi])
+    s.solve(vx, vy, vz, T(g["sphi"][2 * lo:2 * hi + 1]), T(g["sv"][2 * lo:2 * hi + 1]), T(g["lphi"][lo:hi]),
+            tol=float(g["tol"]))
+    torch.cuda.synchronize()
+    np.savez(f"{out}.rank{rank}.npz", vx=vx.cpu().numpy(), vy=vy.cpu().numpy(), vz=vz.cpu().numpy(),
+             x=s.x.cpu().numpy().astype(np.float64), hist=s.history, iters=s.iterations, lo=lo, hi=hi,
+             transport=s.transport, b=buf.b.cpu().numpy().astype(np.float64))
+    s.close()
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     path, out, dtname = sys.argv[4], sys.argv[5], sys.argv[6]
@@ -26,6 +48,12 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if os.environ.get("P2P_TEST_MODE") == "solver":
+        try:
+            solver_mode(rank, world, path, out, dtname, dev)
+        finally:
+            dist.destroy_process_group()
+        return
     try:
         with np.load(path, allow_pickle=False) as z:
             g = {k: z[k] for k in z.files}
