@@ -229,7 +229,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->d2 = p + 4 * cs;
   h->cls = (unsigned char*)(p + 5 * cs);
   h->fuse = env_int("MFS_FUSE_D", 1);
-  h->pd = env_int("MFS_APPLY_PD", 2);
+  h->pd = env_int("MFS_APPLY_PD", 1);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
   const int vec = dt == MFS_F32 ? 4 : 2;
   h->vec_ok = (h->Nz % vec) == 0 && h->Nz >= 2 * vec;
@@ -238,7 +238,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->xchunk = env_int("MFS_APPLY_XCHUNK", 0);
   h->nt = env_int("MFS_APPLY_NT", -1);
   h->nt_auto = env_int("MFS_APPLY_NT_AUTO", 7);
-  h->bpc = env_int("MFS_APPLY_BLOCKS_PER_CU", 2);
+  h->bpc = env_int("MFS_APPLY_BLOCKS_PER_CU", 3);
   h->grid_apply = std::min(kMaxPartials, h->cus * 8);
   h->is_setup = false;
   h->p2p = nullptr;

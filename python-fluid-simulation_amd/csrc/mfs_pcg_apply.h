@@ -31,6 +31,10 @@
 // workgroup barrier that waits on LDS traffic only: global prefetches stay in flight across it
 #define MFS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+#ifndef MFS_MARCH_MIN_WAVES
+#define MFS_MARCH_MIN_WAVES 3      // waves per SIMD the march kernel is compiled for (register budget: 168 VGPRs, no spills)
+#endif
+
 namespace mfs {
 
 constexpr int kApplyBlock = 256;
@@ -252,7 +256,7 @@ struct VSrc {
 // their loads for plane x+1+PD are issued at step x and consumed PD steps later, which keeps PD
 // planes of v per wave in flight -- the march is latency-paced, so bytes in flight are what set its speed.
 template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD>
-__global__ void __launch_bounds__(kApplyBlock)
+__global__ void __launch_bounds__(kApplyBlock, MFS_MARCH_MIN_WAVES)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
                   const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
                   const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
@@ -322,27 +326,30 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       // stage plane x0 (tile + halos) into buffer 0
       T* b0 = smem;
       if (active) vstore<T, VEC>(b0 + Nz + tid * VEC, vc);   // inactive lanes sit past tile_len = in the halo
-      for (int h = tid * VEC; h < Nz; h += kApplyBlock * VEC) {
-        vstore<T, VEC>(b0 + h, src.ld((int64_t)x0 * sx + m0 - Nz + h));
-        vstore<T, VEC>(b0 + Nz + tile_len + h, src.ld((int64_t)x0 * sx + m0 + tile_len + h));
+      for (int s = tid; s < 2 * nzv; s += kApplyBlock) {
+        const bool lo = s < nzv;
+        const int j = lo ? s : s - nzv;
+        vstore<T, VEC>(b0 + (lo ? j * VEC : Nz + tile_len + j * VEC),
+                       src.ld((int64_t)x0 * sx + (lo ? m0 - Nz + j * VEC : m0 + tile_len + j * VEC)));
       }
       MFS_LDS_BARRIER();
     }
+    // The two halo rows of a plane (Nz elements below the tile, Nz above) are 2 * nzv vectors: thread t
+    // owns halo vector t (low row first, then the high row), so the halo prefetch costs ONE vector of
+    // registers per plane in flight; rows with more than 256 halo vectors take the slow path below.
+    const bool hact = LDS && tid < 2 * nzv;
+    const bool hlow = tid < nzv;
+    const int64_t hg = hlow ? m0 - Nz + (int64_t)tid * VEC : m0 + tile_len + (int64_t)(tid - nzv) * VEC;   // in-plane offset
+    const int hl = hlow ? tid * VEC : Nz + tile_len + (tid - nzv) * VEC;                                     // LDS image offset
     // in flight from here on: the operand vector of planes x0+2 .. x0+PD and the halo rows of planes
     // x0+1 .. x0+PD (raw; consumed PD steps after issue)
-    const int hofs = tid * VEC;                             // halo slot owned by this thread (if < Nz)
-    RawVec<T, VEC> Q[PD > 1 ? PD - 1 : 1], HL[PD], HH[PD];
+    RawVec<T, VEC> Q[PD > 1 ? PD - 1 : 1], H[PD];
 #pragma unroll
     for (int k = 0; k < PD - 1; ++k) Q[k] = src.raw((int64_t)min(x0 + 2 + k, x1) * sx + m);
 #pragma unroll
     for (int k = 0; k < PD; ++k) {
-      HL[k] = RawVec<T, VEC>{};
-      HH[k] = RawVec<T, VEC>{};
-      if (LDS && hofs < Nz) {
-        const int64_t hp = (int64_t)min(x0 + 1 + k, x1) * sx + m0;
-        HL[k] = src.raw(hp - Nz + hofs);
-        HH[k] = src.raw(hp + tile_len + hofs);
-      }
+      H[k] = RawVec<T, VEC>{};
+      if (hact) H[k] = src.raw((int64_t)min(x0 + 1 + k, x1) * sx + hg);
     }
 
     for (int x = x0; x < x1; ++x) {
@@ -361,12 +368,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       if (!COMP) cn.cxm = cc.cxp;                           // cx[x+1] was this step's upper-face weight
       unsigned char cls_nn = kClsMixed;
       if (COMP) cls_nn = cls[n2 / VEC];
-      RawVec<T, VEC> hln = {}, hhn = {};                    // halo rows of plane x+1+PD
-      if (LDS && hofs < Nz) {
-        const int64_t hp = (int64_t)min(x + 1 + PD, x1) * sx + m0;
-        hln = src.raw(hp - Nz + hofs);
-        hhn = src.raw(hp + tile_len + hofs);
-      }
+      RawVec<T, VEC> hn = {};                               // this thread's halo vector of plane x+1+PD
+      if (hact) hn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + hg);
       // ---- in-plane neighbours of plane x
       vec_t<T, VEC> vym, vyp;
       double zl, zr;
@@ -393,13 +396,12 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
         if (LDS) {
           T* bn = smem + (cur ^ 1) * buf_elems;
           if (active) vstore<T, VEC>(bn + Nz + tid * VEC, vp);
-          if (hofs < Nz) {
-            vstore<T, VEC>(bn + hofs, src.fin(HL[0]));
-            vstore<T, VEC>(bn + Nz + tile_len + hofs, src.fin(HH[0]));
-          }
-          for (int h = hofs + kApplyBlock * VEC; h < Nz; h += kApplyBlock * VEC) {   // rows longer than one tile
-            vstore<T, VEC>(bn + h, src.ld((int64_t)(x + 1) * sx + m0 - Nz + h));
-            vstore<T, VEC>(bn + Nz + tile_len + h, src.ld((int64_t)(x + 1) * sx + m0 + tile_len + h));
+          if (hact) vstore<T, VEC>(bn + hl, src.fin(H[0]));
+          for (int s = tid + kApplyBlock; s < 2 * nzv; s += kApplyBlock) {   // more halo vectors than threads
+            const bool lo = s < nzv;
+            const int j = lo ? s : s - nzv;
+            vstore<T, VEC>(bn + (lo ? j * VEC : Nz + tile_len + j * VEC),
+                           src.ld((int64_t)(x + 1) * sx + (lo ? m0 - Nz + j * VEC : m0 + tile_len + j * VEC)));
           }
           MFS_LDS_BARRIER();
         }
@@ -408,8 +410,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
         for (int k = 0; k + 1 < PD - 1; ++k) Q[k] = Q[k + 1];
         if (PD > 1) Q[PD - 2] = qn;
 #pragma unroll
-        for (int k = 0; k + 1 < PD; ++k) { HL[k] = HL[k + 1]; HH[k] = HH[k + 1]; }
-        HL[PD - 1] = hln; HH[PD - 1] = hhn;
+        for (int k = 0; k + 1 < PD; ++k) H[k] = H[k + 1];
+        H[PD - 1] = hn;
         base = nb;
       }
     }
