@@ -150,7 +150,9 @@ struct CoefVec {
   unsigned char cls;
 };
 
-template <typename T, int VEC, bool COMP, int NT>
+// LOAD_CXM = false: the caller carries cx[x] over from the previous plane's cxp (the same array element;
+// for a ZERO / REGULAR vector the class constant stands for it on every computed cell)
+template <typename T, int VEC, bool COMP, int NT, bool LOAD_CXM = true>
 __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag, const T* __restrict__ cx,
                                                      const T* __restrict__ cy, const T* __restrict__ cz,
                                                      int64_t b, int64_t sx, int Nz, unsigned char cls) {
@@ -165,7 +167,7 @@ __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag,
     for (int j = 0; j < VEC; ++j) { c.dg[j] = d; c.cxm[j] = f; c.cxp[j] = f; c.cym[j] = f; c.cyp[j] = f; c.czm[j] = f; }
     if (cls == kClsMixed) {
       c.dg = (NT & 1) ? vload_nt<T, VEC>(diag + b) : vload<T, VEC>(diag + b);
-      c.cxm = vload<T, VEC>(cx + b);
+      if (LOAD_CXM) c.cxm = vload<T, VEC>(cx + b);
       c.cxp = (NT & 2) ? vload_nt<T, VEC>(cx + b + sx) : vload<T, VEC>(cx + b + sx);
       c.cym = (NT & 4) ? vload_nt<T, VEC>(cy + b) : vload<T, VEC>(cy + b);
       c.cyp = (NT & 4) ? vload_nt<T, VEC>(cy + b + Nz) : vload<T, VEC>(cy + b + Nz);
@@ -364,8 +366,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
       const RawVec<T, VEC> qn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + m);   // operand vector, plane x+1+PD
       // plane x+1's coefficients (class known since the previous step); class of plane x+2
-      CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls);
-      if (!COMP) cn.cxm = cc.cxp;                           // cx[x+1] was this step's upper-face weight
+      CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT, false>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls);
+      cn.cxm = cc.cxp;                                      // cx[x+1] was this step's upper-face weight
       unsigned char cls_nn = kClsMixed;
       if (COMP) cls_nn = cls[n2 / VEC];
       RawVec<T, VEC> hn = {};                               // this thread's halo vector of plane x+1+PD
