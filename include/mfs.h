@@ -268,6 +268,42 @@ int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_ev
 int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream);
 
 /* ------------------------------------------------------------------------- */
+/* Density solver, 3D -- reference solver/DensityCGSolver3D.py */
+/* ------------------------------------------------------------------------- */
+/* The CG loop of DensityCGSolver3D.solve (:318-345) runs on the pressure engine: call
+ * mfs_pcg3d_setup_density instead of mfs_pcg3d_setup, then bind / solve as for pressure.
+ * Its operator (matvecmul_kernel :118-207) is the pressure stencil with diag counting 1 per
+ * fluid neighbour and the -z tap weighted by wz[x,y,z+1] (kept as written, :184).            */
+int mfs_pcg3d_setup_density(mfs_pcg3d* h, const void* lphi, int lphi_dt,
+                            const void* wx, const void* wy, const void* wz, int w_dt, mfs_stream stream);
+/* replaces initialize_density -- :8-36,255-260: scatters particle mass pm[p] and the (scalar) particle
+ * volume to the 8 surrounding cell centres with fp atomics; px is (P,3) row-major; gm, gvol share g_dt */
+int mfs_density_splat3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3],
+                        const void* px, int px_dt, const void* pm, int pm_dt, double pvol, int64_t num_particles,
+                        void* gm, void* gvol, int g_dt, mfs_stream stream);
+/* replaces fix_volume -- :38-86,262-269 (in place on gvol; the reference's `lvol` argument is unused there) */
+int mfs_density_fix_volume3d(const int64_t gres[3], const double cell_size[3], void* gvol, int g_dt,
+                             const void* sphi, int sphi_dt, const void* lphi, int lphi_dt,
+                             const void* wx, const void* wy, const void* wz, int w_dt, mfs_stream stream);
+/* replaces initialize_solver -- :88-116,271-277 */
+int mfs_density_rhs3d(const int64_t gres[3], double rho0, double dt, const double cell_size[3],
+                      const void* gm, const void* gvol, int g_dt, const void* lphi, int lphi_dt,
+                      const void* wx, const void* wy, const void* wz, int w_dt, void* b, int b_dt, mfs_stream stream);
+/* replaces matvecmul -- :118-207,279-283 (stateless; boundary cells of `out` are not written) */
+int mfs_density_apply3d(const int64_t gres[3], const void* v, void* out, int dt,
+                        const void* wx, const void* wy, const void* wz, int w_dt,
+                        const void* lphi, int lphi_dt, mfs_stream stream);
+/* replaces compute_displacement -- :209-222,285-289: face displacements from the solved field pv */
+int mfs_density_displacement3d(const int64_t gres[3], double dt, const double cell_size[3],
+                               void* dx, void* dy, void* dz, int d_dt, const void* pv, int pv_dt,
+                               const void* lphi, int lphi_dt, mfs_stream stream);
+/* replaces apply_displacement -- :224-253,291-296: px[:, axis] += trilinear sample of the face array d
+ * (shape dshape, samples at (index + grid_bias) * cell_size + bound_min)                              */
+int mfs_density_advect3d(void* px, int px_dt, int64_t num_particles, const void* d, int d_dt,
+                         const int64_t dshape[3], const double bound_min[3], const double cell_size[3],
+                         const double grid_bias[3], int axis, mfs_stream stream);
+
+/* ------------------------------------------------------------------------- */
 /* Pressure, 2D (BASELINE config 1) -- reference solver/PressureCGSolver2D.py    */
 /* ------------------------------------------------------------------------- */
 /* replaces initialize_solver -- solver/PressureCGSolver2D.py:6-44,122-126 */

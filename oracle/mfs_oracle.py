@@ -654,3 +654,165 @@ def nb_boundary_condition(gres, gv, gm, sphi, sv, dx, dv):
             proj = np.where(s < 0, s, 0.0) * sn[a] * sn_inv
             out = -proj * (1.0 - ndist)
         dv[a][I] = np.where(ndist >= 1, 0.0, out).astype(dv[a].dtype)
+
+
+# =============================================================================
+# density solver, 3D -- solver/DensityCGSolver3D.py
+# =============================================================================
+def _particle_cell(px, bound_min, cell_size, bias):
+    """base index and |gx - x| / cell_size weights of every particle (:17-22 / :235-239)."""
+    x = np.asarray(px, F64)
+    bmin, cs, bias = (np.asarray(a, F64) for a in (bound_min, cell_size, bias))
+    gi = np.floor((x - bmin) / cs - bias).astype(np.int64)
+    gx = (gi + bias) * cs + bmin
+    return gi, np.abs(gx - x) / cs
+
+
+def _corner_weights(w, ix, iy, iz):
+    cw = lambda i, wd: i + ((-1) ** i) * (1 - wd)  # noqa: E731
+    return cw(ix, w[:, 0]) * cw(iy, w[:, 1]) * cw(iz, w[:, 2])
+
+
+def density_splat3d(bound_min, cell_size, gres, px, pm, pvol, gm, gvol):
+    """initialize_density_kernel :8-36 (order of the atomic adds is unspecified in the reference)."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    gi, w = _particle_cell(px, bound_min, cell_size, (0.5, 0.5, 0.5))
+    m = np.asarray(pm, F64)
+    for ix in (0, 1):
+        for iy in (0, 1):
+            for iz in (0, 1):
+                cx = np.clip(gi[:, 0] + ix, 0, Nx - 1)
+                cy = np.clip(gi[:, 1] + iy, 0, Ny - 1)
+                cz = np.clip(gi[:, 2] + iz, 0, Nz - 1)
+                weight = _corner_weights(w, ix, iy, iz)
+                np.add.at(gm, (cx, cy, cz), weight * m)
+                np.add.at(gvol, (cx, cy, cz), weight * float(pvol))
+
+
+def _nonsolid_frac(gres, wx, wy, wz):
+    Nx, Ny, Nz = (int(g) for g in gres)
+    a = lambda A, dx, dy, dz: np.asarray(A, F64)[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy, 1 + dz:Nz - 1 + dz]  # noqa: E731
+    return (a(wx, 0, 0, 0) + a(wx, 1, 0, 0) + a(wy, 0, 0, 0) + a(wy, 0, 1, 0) + a(wz, 0, 0, 0) + a(wz, 0, 0, 1)) / 6
+
+
+def density_fix_volume3d(cell_size, gres, lvol, gvol, sphi, lphi, wx, wy, wz):
+    """fix_volume_kernel :38-86 (`lvol` is unused there, as in the reference)."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    if min(Nx, Ny, Nz) < 3:
+        return
+    cs = np.asarray(cell_size, F64)
+    cvol, dx = float(np.prod(cs)), float(np.min(cs))
+    I = (slice(1, Nx - 1), slice(1, Ny - 1), slice(1, Nz - 1))
+    sh = lambda A, ox, oy, oz: np.asarray(A, F64)[1 + ox:Nx - 1 + ox, 1 + oy:Ny - 1 + oy, 1 + oz:Nz - 1 + oz]  # noqa: E731
+    fluid_vol = np.asarray(gvol, F64)[I]
+    near_solid = np.asarray(sphi, F64)[3:2 * Nx - 2:2, 3:2 * Ny - 2:2, 3:2 * Nz - 2:2] < dx
+    internal = sh(lphi, 0, 0, 0) < 0
+    for off in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+        internal = internal & (sh(lphi, *off) < 0)
+    fluid_vol = np.where(internal & ~near_solid, cvol, fluid_vol)
+    gvol[I] = np.minimum(fluid_vol, cvol * _nonsolid_frac(gres, wx, wy, wz))
+
+
+def density_rhs3d(rho0, dt, gres, cell_size, gm, gvol, lphi, wx, wy, wz, b):
+    """initialize_solver_kernel :88-116."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    if min(Nx, Ny, Nz) < 3:
+        return
+    cvol = float(np.prod(np.asarray(cell_size, F64)))
+    I = (slice(1, Nx - 1), slice(1, Ny - 1), slice(1, Nz - 1))
+    solid_vol = (1 - _nonsolid_frac(gres, wx, wy, wz)) * cvol
+    solid_mass = rho0 * solid_vol
+    cell_mass = np.asarray(gm, F64)[I] + solid_mass
+    cell_vol = np.asarray(gvol, F64)[I] + solid_vol
+    frac = cell_mass / np.maximum(cell_vol, 1e-10) / rho0
+    frac = np.where(cell_mass < 1e-10, 1.0, frac)
+    frac = np.maximum(0.5, np.minimum(1.5, frac))
+    b[I] = np.where(np.asarray(lphi, F64)[I] >= 0, 0.0, (1 - frac) / dt)
+
+
+def density_apply3d(gres, v, out, wx, wy, wz, lphi):
+    """matvecmul_kernel :118-207: diag counts 1 per fluid neighbour (1/theta per non-fluid one), and the
+    -z tap is weighted by wz[x,y,z+1] (:184, kept as written)."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    if min(Nx, Ny, Nz) < 3:
+        return
+    I = (slice(1, Nx - 1), slice(1, Ny - 1), slice(1, Nz - 1))
+    sh = lambda a, dx, dy, dz: np.asarray(a, F64)[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy, 1 + dz:Nz - 1 + dz]  # noqa: E731
+    phi = sh(lphi, 0, 0, 0)
+    val = np.zeros_like(phi)
+    diag = np.zeros_like(phi)
+    nbrs = [((1, 0, 0), sh(wx, 1, 0, 0)), ((-1, 0, 0), sh(wx, 0, 0, 0)),
+            ((0, 1, 0), sh(wy, 0, 1, 0)), ((0, -1, 0), sh(wy, 0, 0, 0)),
+            ((0, 0, 1), sh(wz, 0, 0, 1)), ((0, 0, -1), sh(wz, 0, 0, 1))]
+    for off, w in nbrs:
+        nphi = sh(lphi, *off)
+        nf = nphi < 0
+        val = val - np.where(nf, w * sh(v, *off), 0.0)
+        diag = diag + np.where(nf, 1.0, 1.0 / _theta(phi, nphi))
+    val = val + diag * sh(v, 0, 0, 0)
+    out[I] = np.where(phi < 0, val, 0.0)
+
+
+def density_displacement3d(gres, dt, cell_size, dx, dy, dz, pv, lphi):
+    """compute_displacement_kernel :209-222 (x,y,z in [1, N-1])."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    cs = np.asarray(cell_size, F64)
+    P, L = np.asarray(pv, F64), np.asarray(lphi, F64)
+    c = (slice(1, Nx), slice(1, Ny), slice(1, Nz))
+    for out, ax in ((dx, 0), (dy, 1), (dz, 2)):
+        m = tuple(slice(0, n - 1) if a == ax else slice(1, n) for a, n in enumerate((Nx, Ny, Nz)))
+        th = np.minimum(1.0, np.maximum(0.01, edge_in_fraction(L[c], L[m])))
+        out[c] = (P[c] - P[m]) * dt * cs[ax] / th
+
+
+def density_advect3d(px, d, bound_min, cell_size, grid_bias, axis):
+    """apply_displacement_kernel :224-253: px[:, axis] += trilinear sample of d (in the kernel's add order)."""
+    s = d.shape
+    gi, w = _particle_cell(px, bound_min, cell_size, grid_bias)
+    pos = px[:, axis].copy()
+    for ix in (0, 1):
+        for iy in (0, 1):
+            for iz in (0, 1):
+                cx = np.clip(gi[:, 0] + ix, 0, s[0] - 1)
+                cy = np.clip(gi[:, 1] + iy, 0, s[1] - 1)
+                cz = np.clip(gi[:, 2] + iz, 0, s[2] - 1)
+                pos = (pos + _corner_weights(w, ix, iy, iz) * np.asarray(d, F64)[cx, cy, cz]).astype(px.dtype)
+    px[:, axis] = pos
+
+
+class DensityCGSolver3D:
+    """solver/DensityCGSolver3D.py:298-350 on numpy arrays."""
+
+    def __init__(self, gres, bound_min, bound_size):
+        self.gres = tuple(int(g) for g in gres)
+        self.bound_min = np.asarray(bound_min, F64)
+        self.cell_size = np.broadcast_to(np.asarray(bound_size, F64), (3,)) / np.asarray(self.gres, F64)
+        Nx, Ny, Nz = self.gres
+        self.d, self.r, self.q, self.b, self.x, self.m, self.vol = (np.zeros(self.gres) for _ in range(7))
+        self.wx, self.dx = np.zeros((Nx + 1, Ny, Nz)), np.zeros((Nx + 1, Ny, Nz))
+        self.wy, self.dy = np.zeros((Nx, Ny + 1, Nz)), np.zeros((Nx, Ny + 1, Nz))
+        self.wz, self.dz = np.zeros((Nx, Ny, Nz + 1)), np.zeros((Nx, Ny, Nz + 1))
+        self.max_iter = Nx * Ny * Nz
+        self.history = []
+        self.iterations = 0
+
+    def solve(self, rho0, dt, px, pm, pvol, vx, vy, vz, sphi, sv, lphi, lvol, wx=None, wy=None, wz=None, tol=1e-3,
+              max_iter=None, raise_on_fail=True):
+        if wx is None or wy is None or wz is None:
+            compute_solid_frac3d(self.gres, sphi, self.wx, self.wy, self.wz)
+            wx, wy, wz = self.wx, self.wy, self.wz
+        self.m *= 0
+        self.vol *= 0
+        self.x *= 0
+        density_splat3d(self.bound_min, self.cell_size, self.gres, px, pm, pvol, self.m, self.vol)
+        density_fix_volume3d(self.cell_size, self.gres, lvol, self.vol, sphi, lphi, wx, wy, wz)
+        density_rhs3d(rho0, dt, self.gres, self.cell_size, self.m, self.vol, lphi, wx, wy, wz, self.b)
+        self.history = []
+        ap = lambda V, O: density_apply3d(self.gres, V[0], O[0], wx, wy, wz, lphi)  # noqa: E731
+        self.iterations, self.delta, self.alpha, self.beta = cg(
+            ap, self.b, self.x, self.d, self.r, self.q, tol,
+            self.max_iter if max_iter is None else max_iter, self.history, raise_on_fail)
+        density_displacement3d(self.gres, dt, self.cell_size, self.dx, self.dy, self.dz, self.x, lphi)
+        density_advect3d(px, self.dx, self.bound_min, self.cell_size, (0, 0.5, 0.5), 0)
+        density_advect3d(px, self.dy, self.bound_min, self.cell_size, (0.5, 0, 0.5), 1)
+        density_advect3d(px, self.dz, self.bound_min, self.cell_size, (0.5, 0.5, 0), 2)

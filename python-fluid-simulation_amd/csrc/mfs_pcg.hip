@@ -20,10 +20,14 @@ namespace mfs {
 
 // ---------------------------------------------------------------- setup -----
 // diag / masked lower-face weights from lphi and w (PressureCGSolver3D.py:59-126).
-template <typename T>
+// DENSITY: the operator of solver/DensityCGSolver3D.py:118-207 instead -- same off-diagonal weights except
+// the -z tap, which reads wz[x,y,z+1] (:184; kept as written) -> cz2; diag counts 1 per fluid neighbour and
+// 1/theta per non-fluid one (:135-199) instead of the face weights.
+template <typename T, bool DENSITY>
 __global__ void __launch_bounds__(kBlock)
 k_pcg_setup(int Nx, int Ny, int Nz, const void* lphi, int ldt, const void* wx, const void* wy, const void* wz,
-            int wdt, T* __restrict__ diag, T* __restrict__ cx, T* __restrict__ cy, T* __restrict__ cz) {
+            int wdt, T* __restrict__ diag, T* __restrict__ cx, T* __restrict__ cy, T* __restrict__ cz,
+            T* __restrict__ cz2) {
   const int64_t n = (int64_t)Nx * Ny * Nz;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -41,10 +45,12 @@ k_pcg_setup(int Nx, int Ny, int Nz, const void* lphi, int ldt, const void* wx, c
   cx[i] = (T)((fl && pxm < 0) ? wxm : 0.0);
   cy[i] = (T)((fl && pym < 0) ? wym : 0.0);
   cz[i] = (T)((fl && pzm < 0) ? wzm : 0.0);
+  if (DENSITY) cz2[i] = (T)((fl && pzm < 0 && z > 0) ? ldx(wz, wdt, ((int64_t)x * Ny + y) * (Nz + 1) + z + 1) : 0.0);
   double dg = 0.0;
   const bool interior = x > 0 && x < Nx - 1 && y > 0 && y < Ny - 1 && z > 0 && z < Nz - 1;
   if (interior && fl) {
     auto acc = [&](double nphi, double w) {
+      if (DENSITY) w = 1.0;
       if (nphi < 0) dg += w;
       else dg += w / fmin(1.0, fmax(0.01, phi / (phi - nphi)));
     };
@@ -69,6 +75,8 @@ struct mfs_pcg3d {
   char* ws;
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
+  void* cz2;                   // asym only: weight of the -z tap (the density operator, DensityCGSolver3D.py:184)
+  int asym;                    // 1: set up by mfs_pcg3d_setup_density
   void* d2;                    // ping-pong partner of the bound d (fused direction update)
   int pd;                      // prefetch depth (planes) of the operand stream in the LDS march: 1 or 2
   int fuse;                    // 1: native loop folds d = r + beta d into the stencil launch
@@ -91,11 +99,12 @@ template <typename T, int VEC>
 static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int xb2, int xe2, double* partial,
                           const double* done, hipStream_t st, int* grid_out, const FuseArgs* fz = nullptr) {
   const T *dg = (const T*)h->diag, *cx = (const T*)h->cx, *cy = (const T*)h->cy, *cz = (const T*)h->cz;
+  const T* cz2 = (const T*)h->cz2;                 // the density operator's -z weights (asym only)
+  const bool asym = h->asym != 0;
   const int nzv = h->Nz / VEC;
   const int64_t ipp = (int64_t)(h->Ny - 2) * nzv;
-  int variant = h->variant;
-  const int ry = variant == 3 ? 2 : (variant == 4 ? 4 : 1);
-  const size_t lds = 2 * ((size_t)ry * kApplyBlock * VEC + 2 * (size_t)h->Nz) * sizeof(T);
+  int variant = asym ? std::max(1, h->variant) : h->variant;
+  const size_t lds = 2 * ((size_t)kApplyBlock * VEC + 2 * (size_t)h->Nz) * sizeof(T);
   if (variant >= 2 && lds > 64 * 1024) variant = 1;          // absurdly long rows: skip the LDS image
   const int xchunk = std::max(0, h->xchunk);   // 0 = no cap on the length of one march
   ApplyArgs a{h->Nx, h->Ny, h->Nz, xb, xe, xchunk, xb2, xe2};
@@ -107,68 +116,47 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
                        partial, done);
     *grid_out = grid;
   } else {
-    const int64_t tiles = (ipp + (int64_t)ry * kApplyBlock - 1) / ((int64_t)ry * kApplyBlock);
+    const int64_t tiles = (ipp + kApplyBlock - 1) / kApplyBlock;
     const int64_t total = tiles * np;                 // (tile, plane) pairs, cut into `grid` equal segments
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kMaxPartials, h->cus * h->bpc), total));
     // Nontemporal loads for the once-read coefficient streams pay off only when the
     // apply's working set (6 arrays) cannot sit in the 256 MiB Infinity Cache anyway;
     // below that, default caching lets the next iteration hit on-die.  nt < 0 = auto.
     // bit 0: diag, cz   bit 1: cx   bit 2: cy   -- the once-per-iteration coefficient streams.
-    // < 0 = auto: all of them when the apply's six arrays exceed the Infinity Cache.
-    const int nt = h->nt < 0 ? ((6.0 * (double)h->n * sizeof(T) > 200e6) ? h->nt_auto : 0) : (h->nt & 7);
-#define MFS_MARCH(LDSF, NTV, CMP) \
-    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV, CMP, false, 1>), dim3(grid), dim3(kApplyBlock), LDSF ? lds : 0, st, \
-                       v, out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, \
-                       (const double*)nullptr)
-#define MFS_MARCH_F(NTV, CMP, PDV) \
-    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, PDV>), dim3(grid), dim3(kApplyBlock), lds, st, v, \
-                       out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)fz->r, (const T*)fz->d_old, \
-                       (T*)fz->d_new, h->c.scal + S_BETA)
-#define MFS_MARCH_P(NTV, CMP, PDV) \
-    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, false, PDV>), dim3(grid), dim3(kApplyBlock), lds, st, v, \
-                       out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)nullptr, (const T*)nullptr, (T*)nullptr, \
-                       (const double*)nullptr)
+    int nt = h->nt < 0 ? ((6.0 * (double)h->n * sizeof(T) > 200e6) ? h->nt_auto : 0) : (h->nt & 7);
     const bool comp = h->compress != 0 && VEC > 1;
-#define MFS_MARCH_R(NTV, CMP, RYV) \
-    hipLaunchKernelGGL((k_pcg_apply_march_r<T, VEC, NTV, CMP, RYV>), dim3(grid), dim3(kApplyBlock), lds, st, v, out, dg, \
-                       cx, cy, cz, h->cls, a, partial, done)
-    const int pd = h->pd >= 2 ? 2 : 1;
-    if (fz) {   // direction update folded in: LDS march only (the caller checked variant == 2 and VEC > 1)
-      if (pd == 2) {
-        if (comp) { if (nt) MFS_MARCH_F(7, true, 2); else MFS_MARCH_F(0, true, 2); }
-        else      { if (nt) MFS_MARCH_F(7, false, 2); else MFS_MARCH_F(0, false, 2); }
-      } else {
-        if (comp) { if (nt) MFS_MARCH_F(7, true, 1); else MFS_MARCH_F(0, true, 1); }
-        else      { if (nt) MFS_MARCH_F(7, false, 1); else MFS_MARCH_F(0, false, 1); }
-      }
-    } else if (variant == 2 && pd == 2) {
-      if (comp) { if (nt) MFS_MARCH_P(7, true, 2); else MFS_MARCH_P(0, true, 2); }
-      else      { if (nt) MFS_MARCH_P(7, false, 2); else MFS_MARCH_P(0, false, 2); }
-    } else if (variant == 3 || variant == 4) {
-      if (variant == 3) {
-        if (comp) { if (nt) MFS_MARCH_R(7, true, 2); else MFS_MARCH_R(0, true, 2); }
-        else      { if (nt) MFS_MARCH_R(7, false, 2); else MFS_MARCH_R(0, false, 2); }
-      } else {
-        if (comp) { if (nt) MFS_MARCH_R(7, true, 4); else MFS_MARCH_R(0, true, 4); }
-        else      { if (nt) MFS_MARCH_R(7, false, 4); else MFS_MARCH_R(0, false, 4); }
-      }
-    } else if (variant == 2 && comp) {
-      if (nt) MFS_MARCH(true, 7, true); else MFS_MARCH(true, 0, true);
-    } else if (variant == 2) {
+    const int pd = (h->pd >= 2 && !asym) ? 2 : 1;
+    // <LDS, NT, COMP, FUSE, PD, ASYM> with the fused operands (null unless fz)
+#define MFS_GO(LDSF, NTV, CMP, FUS, PDV, ASY)                                                                          \
+    hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, LDSF, NTV, CMP, FUS, PDV, ASY>), dim3(grid), dim3(kApplyBlock),      \
+                       LDSF ? lds : 0, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done,                          \
+                       (const T*)(fz ? fz->r : nullptr), (const T*)(fz ? fz->d_old : nullptr),                         \
+                       (T*)(fz ? fz->d_new : nullptr), (const double*)(fz ? h->c.scal + S_BETA : nullptr), cz2)
+#define MFS_GO_NT_CMP(FUS, PDV, ASY)                                                   \
+    do {                                                                               \
+      if (comp) { if (nt) MFS_GO(true, 7, true, FUS, PDV, ASY); else MFS_GO(true, 0, true, FUS, PDV, ASY); }   \
+      else      { if (nt) MFS_GO(true, 7, false, FUS, PDV, ASY); else MFS_GO(true, 0, false, FUS, PDV, ASY); } \
+    } while (0)
+    if (variant == 1) {                               // marching without the LDS image (fallback / A-B)
+      MFS_REQUIRE(fz == nullptr, "the fused direction update needs the LDS march");
+      if (asym) { if (nt) MFS_GO(false, 1, false, false, 1, true); else MFS_GO(false, 0, false, false, 1, true); }
+      else      { if (nt) MFS_GO(false, 1, false, false, 1, false); else MFS_GO(false, 0, false, false, 1, false); }
+    } else if (asym) {
+      if (fz) MFS_GO_NT_CMP(true, 1, true); else MFS_GO_NT_CMP(false, 1, true);
+    } else if (fz) {
+      if (pd == 2) MFS_GO_NT_CMP(true, 2, false); else MFS_GO_NT_CMP(true, 1, false);
+    } else if (comp || nt == 0 || nt == 7) {
+      if (pd == 2) MFS_GO_NT_CMP(false, 2, false); else MFS_GO_NT_CMP(false, 1, false);
+    } else {                                          // dense access with a partial nontemporal mask (A-B of the hints)
       switch (nt) {
-        case 0: MFS_MARCH(true, 0, false); break;
-        case 1: MFS_MARCH(true, 1, false); break;
-        case 3: MFS_MARCH(true, 3, false); break;
-        case 5: MFS_MARCH(true, 5, false); break;
-        default: MFS_MARCH(true, 7, false); break;
+        case 1: MFS_GO(true, 1, false, false, 1, false); break;
+        case 3: MFS_GO(true, 3, false, false, 1, false); break;
+        case 5: MFS_GO(true, 5, false, false, 1, false); break;
+        default: MFS_GO(true, 7, false, false, 1, false); break;
       }
-    } else {
-      if (nt) MFS_MARCH(false, 1, false); else MFS_MARCH(false, 0, false);
     }
-#undef MFS_MARCH
-#undef MFS_MARCH_F
-#undef MFS_MARCH_P
-#undef MFS_MARCH_R
+#undef MFS_GO_NT_CMP
+#undef MFS_GO
     *grid_out = grid;
   }
   MFS_LAUNCH_CHECK();
@@ -205,7 +193,7 @@ extern "C" {
 size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   const int64_t n = gres[0] * gres[1] * gres[2];
-  return core_ws_bytes() + 5 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096);
+  return core_ws_bytes() + 6 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096);
 }
 
 int64_t mfs_pcg3d_history_capacity(void) { return kHistCap; }
@@ -227,7 +215,9 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   const size_t cs = coef_stride(h->n, h->c.elt);
   h->diag = p; h->cx = p + cs; h->cy = p + 2 * cs; h->cz = p + 3 * cs;
   h->d2 = p + 4 * cs;
-  h->cls = (unsigned char*)(p + 5 * cs);
+  h->cz2 = p + 5 * cs;
+  h->asym = 0;
+  h->cls = (unsigned char*)(p + 6 * cs);
   h->fuse = env_int("MFS_FUSE_D", 1);
   h->pd = env_int("MFS_APPLY_PD", 1);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
@@ -259,35 +249,45 @@ int mfs_pcg3d_destroy(mfs_pcg3d* h) {
   return MFS_OK;
 }
 
-int mfs_pcg3d_setup(mfs_pcg3d* h, const void* lphi, int lphi_dt, const void* wx, const void* wy, const void* wz,
-                    int w_dt, mfs_stream stream) {
+static int pcg_setup_impl(mfs_pcg3d* h, const void* lphi, int lphi_dt, const void* wx, const void* wy, const void* wz,
+                          int w_dt, bool density, hipStream_t st) {
   MFS_REQUIRE(h && lphi && wx && wy && wz, "null argument");
   MFS_REQUIRE(dtype_ok(lphi_dt) && dtype_ok(w_dt), "dtype");
   const int grid = cdiv(h->n, kBlock);
-  if (h->dt == MFS_F32)
-    hipLaunchKernelGGL((k_pcg_setup<float>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h->Nx, h->Ny, h->Nz,
-                       lphi, lphi_dt, wx, wy, wz, w_dt, (float*)h->diag, (float*)h->cx, (float*)h->cy, (float*)h->cz);
-  else
-    hipLaunchKernelGGL((k_pcg_setup<double>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h->Nx, h->Ny, h->Nz,
-                       lphi, lphi_dt, wx, wy, wz, w_dt, (double*)h->diag, (double*)h->cx, (double*)h->cy,
-                       (double*)h->cz);
+#define MFS_SETUP(TT, DEN)                                                                                         \
+  hipLaunchKernelGGL((k_pcg_setup<TT, DEN>), dim3(grid), dim3(kBlock), 0, st, h->Nx, h->Ny, h->Nz, lphi, lphi_dt, wx, \
+                     wy, wz, w_dt, (TT*)h->diag, (TT*)h->cx, (TT*)h->cy, (TT*)h->cz, (TT*)h->cz2)
+  if (h->dt == MFS_F32) { if (density) MFS_SETUP(float, true); else MFS_SETUP(float, false); }
+  else                  { if (density) MFS_SETUP(double, true); else MFS_SETUP(double, false); }
+#undef MFS_SETUP
   MFS_LAUNCH_CHECK();
+  h->asym = density ? 1 : 0;
   if (h->vec_ok) {   // class byte per z-vector for the compressed coefficient access
     if (h->dt == MFS_F32) {
       const int64_t nvec = h->n / 4;
-      hipLaunchKernelGGL((k_pcg_classify<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)h->diag, (const float*)h->cx, (const float*)h->cy, (const float*)h->cz, h->Nx,
-                         h->Ny, h->Nz, h->cls);
+      hipLaunchKernelGGL((k_pcg_classify<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, (const float*)h->diag,
+                         (const float*)h->cx, (const float*)h->cy, (const float*)h->cz, h->Nx, h->Ny, h->Nz, h->cls,
+                         density ? (const float*)h->cz2 : (const float*)nullptr);
     } else {
       const int64_t nvec = h->n / 2;
-      hipLaunchKernelGGL((k_pcg_classify<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
-                         (const double*)h->diag, (const double*)h->cx, (const double*)h->cy, (const double*)h->cz,
-                         h->Nx, h->Ny, h->Nz, h->cls);
+      hipLaunchKernelGGL((k_pcg_classify<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, (const double*)h->diag,
+                         (const double*)h->cx, (const double*)h->cy, (const double*)h->cz, h->Nx, h->Ny, h->Nz, h->cls,
+                         density ? (const double*)h->cz2 : (const double*)nullptr);
     }
     MFS_LAUNCH_CHECK();
   }
   h->is_setup = true;
   return MFS_OK;
+}
+
+int mfs_pcg3d_setup(mfs_pcg3d* h, const void* lphi, int lphi_dt, const void* wx, const void* wy, const void* wz,
+                    int w_dt, mfs_stream stream) {
+  return pcg_setup_impl(h, lphi, lphi_dt, wx, wy, wz, w_dt, false, (hipStream_t)stream);
+}
+
+int mfs_pcg3d_setup_density(mfs_pcg3d* h, const void* lphi, int lphi_dt, const void* wx, const void* wy,
+                            const void* wz, int w_dt, mfs_stream stream) {
+  return pcg_setup_impl(h, lphi, lphi_dt, wx, wy, wz, w_dt, true, (hipStream_t)stream);
 }
 
 int mfs_pcg3d_apply(mfs_pcg3d* h, const void* v, void* out, int64_t x_begin, int64_t x_end, mfs_stream stream) {
@@ -309,7 +309,7 @@ void* mfs_pcg3d_scalars(mfs_pcg3d* h) { return h ? h->c.scal : nullptr; }
 
 int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int nontemporal) {
   MFS_REQUIRE(h, "null handle");
-  MFS_REQUIRE(variant >= 0 && variant <= 4, "variant: 0 direct, 1 march, 2 march+LDS, 3 / 4 march+LDS with 2 / 4 vectors per thread");
+  MFS_REQUIRE(variant >= 0 && variant <= 2, "variant: 0 direct, 1 march, 2 march+LDS");
   MFS_REQUIRE(xchunk >= 0 && blocks_per_cu >= 1, "xchunk must be >= 0 (0 = no cap), blocks_per_cu >= 1");
   h->variant = variant; h->xchunk = xchunk; h->bpc = blocks_per_cu;
   h->nt = nontemporal < 0 ? -1 : (nontemporal & 7);
@@ -519,7 +519,7 @@ int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_strea
 // Slab loop over peer-to-peer windows (mfs_pcg_slab.h): one rank of a grid cut into x-slabs.
 // ----------------------------------------------------------------------------------------------
 static bool slab_ok(const mfs_pcg3d* h) {
-  return h->p2p && h->p2p->connected && native_fuse_ok(h) &&
+  return h->p2p && h->p2p->connected && native_fuse_ok(h) && !h->asym &&
          (size_t)h->Ny * h->Nz * h->c.elt == h->p2p->plane_bytes;
 }
 

@@ -5,6 +5,9 @@
 //   out[c] = diag[c] v[c] - cx[x+1] v[x+1] - cx[x] v[x-1] - cy[y+1] v[y+1]
 //            - cy[y] v[y-1] - cz[z+1] v[z+1] - cz[z] v[z-1]
 //   accumulated in the reference's order (+x -x +y -y +z -z, then diag), in fp64.
+//   ASYM: the same launch serves the density solver's operator (solver/DensityCGSolver3D.py:
+//   118-207), which differs in `diag` (built by its own setup) and in the -z tap, whose weight
+//   is a fifth coefficient array cz2 (the reference reads wz[x,y,z+1] there, :184).
 //
 // Algorithmic HBM traffic: v, diag, cx, cy, cz read once, out written once
 // = 6 scalars per cell.  Everything below is about making the
@@ -48,7 +51,8 @@ __device__ __forceinline__ void stencil_vec(T* __restrict__ out_ptr, vec_t<T, VE
                                             vec_t<T, VEC> vxm, vec_t<T, VEC> vyp, vec_t<T, VEC> vym,
                                             vec_t<T, VEC> dg, vec_t<T, VEC> cxp, vec_t<T, VEC> cxm,
                                             vec_t<T, VEC> cyp, vec_t<T, VEC> cym, vec_t<T, VEC> czm, double zl,
-                                            double zr, double czr, bool first, bool last, bool active, double& acc) {
+                                            double zr, double czr, bool first, bool last, bool active, double& acc,
+                                            vec_t<T, VEC> czm2) {   // czm2: weight of the -z tap (= czm unless ASYM)
   vec_t<T, VEC> o;
 #ifdef MFS_APPLY_NATIVE_MATH   // experiment: arithmetic in the storage type
   typedef T C;
@@ -66,7 +70,7 @@ __device__ __forceinline__ void stencil_vec(T* __restrict__ out_ptr, vec_t<T, VE
     val -= (C)cyp[j] * (C)vyp[j];
     val -= (C)cym[j] * (C)vym[j];
     val -= czp * zp;
-    val -= (C)czm[j] * zm;
+    val -= (C)czm2[j] * zm;
     val += (C)dg[j] * (C)vc[j];
     o[j] = (T)val;
     const bool bnd = (first && j == 0) || (last && j == VEC - 1);
@@ -125,7 +129,8 @@ k_pcg_apply_direct(const T* __restrict__ v, T* __restrict__ out, const T* __rest
     stencil_vec<T, VEC>(out + base, vc, vload<T, VEC>(v + base + sx), vload<T, VEC>(v + base - sx),
                         vload<T, VEC>(v + base + sy), vload<T, VEC>(v + base - sy), vload<T, VEC>(diag + base),
                         vload<T, VEC>(cx + base + sx), vload<T, VEC>(cx + base), vload<T, VEC>(cy + base + sy),
-                        vload<T, VEC>(cy + base), vload<T, VEC>(cz + base), zl, zr, czr, first, last, true, acc);
+                        vload<T, VEC>(cy + base), vload<T, VEC>(cz + base), zl, zr, czr, first, last, true, acc,
+                        vload<T, VEC>(cz + base));
   }
   const double tot = block_sum<kApplyBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -146,16 +151,17 @@ enum : unsigned char { kClsZero = 0, kClsRegular = 1, kClsMixed = 2 };
 
 template <typename T, int VEC>
 struct CoefVec {
-  vec_t<T, VEC> dg, cxm, cxp, cym, cyp, czm;
+  vec_t<T, VEC> dg, cxm, cxp, cym, cyp, czm, czm2;
   unsigned char cls;
 };
 
 // LOAD_CXM = false: the caller carries cx[x] over from the previous plane's cxp (the same array element;
 // for a ZERO / REGULAR vector the class constant stands for it on every computed cell)
-template <typename T, int VEC, bool COMP, int NT, bool LOAD_CXM = true>
+template <typename T, int VEC, bool COMP, int NT, bool LOAD_CXM = true, bool ASYM = false>
 __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag, const T* __restrict__ cx,
                                                      const T* __restrict__ cy, const T* __restrict__ cz,
-                                                     int64_t b, int64_t sx, int Nz, unsigned char cls) {
+                                                     int64_t b, int64_t sx, int Nz, unsigned char cls,
+                                                     const T* __restrict__ cz2 = nullptr) {
   CoefVec<T, VEC> c;
   c.cls = cls;
   if (COMP) {
@@ -164,7 +170,7 @@ __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag,
     // loaded registers, so the loads stay in flight until the stencil consumes them.
     const T f = cls == kClsRegular ? (T)1 : (T)0, d = cls == kClsRegular ? (T)6 : (T)0;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { c.dg[j] = d; c.cxm[j] = f; c.cxp[j] = f; c.cym[j] = f; c.cyp[j] = f; c.czm[j] = f; }
+    for (int j = 0; j < VEC; ++j) { c.dg[j] = d; c.cxm[j] = f; c.cxp[j] = f; c.cym[j] = f; c.cyp[j] = f; c.czm[j] = f; c.czm2[j] = f; }
     if (cls == kClsMixed) {
       c.dg = (NT & 1) ? vload_nt<T, VEC>(diag + b) : vload<T, VEC>(diag + b);
       if (LOAD_CXM) c.cxm = vload<T, VEC>(cx + b);
@@ -172,7 +178,9 @@ __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag,
       c.cym = (NT & 4) ? vload_nt<T, VEC>(cy + b) : vload<T, VEC>(cy + b);
       c.cyp = (NT & 4) ? vload_nt<T, VEC>(cy + b + Nz) : vload<T, VEC>(cy + b + Nz);
       c.czm = (NT & 1) ? vload_nt<T, VEC>(cz + b) : vload<T, VEC>(cz + b);
+      if (ASYM) c.czm2 = (NT & 1) ? vload_nt<T, VEC>(cz2 + b) : vload<T, VEC>(cz2 + b);
     }
+    if (!ASYM) c.czm2 = c.czm;
     return c;
   }
   c.dg = (NT & 1) ? vload_nt<T, VEC>(diag + b) : vload<T, VEC>(diag + b);
@@ -181,6 +189,8 @@ __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag,
   c.cym = (NT & 4) ? vload_nt<T, VEC>(cy + b) : vload<T, VEC>(cy + b);
   c.cyp = (NT & 4) ? vload_nt<T, VEC>(cy + b + Nz) : vload<T, VEC>(cy + b + Nz);
   c.czm = (NT & 1) ? vload_nt<T, VEC>(cz + b) : vload<T, VEC>(cz + b);
+  if (ASYM) c.czm2 = (NT & 1) ? vload_nt<T, VEC>(cz2 + b) : vload<T, VEC>(cz2 + b);
+  else c.czm2 = c.czm;
   return c;
 }
 
@@ -188,7 +198,8 @@ __device__ __forceinline__ CoefVec<T, VEC> coef_load(const T* __restrict__ diag,
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 k_pcg_classify(const T* __restrict__ diag, const T* __restrict__ cx, const T* __restrict__ cy,
-               const T* __restrict__ cz, int Nx, int Ny, int Nz, unsigned char* __restrict__ cls) {
+               const T* __restrict__ cz, int Nx, int Ny, int Nz, unsigned char* __restrict__ cls,
+               const T* __restrict__ cz2) {   // cz2: the asymmetric operator's -z weights, or null
   const int nzv = Nz / VEC;
   const int64_t nvec = (int64_t)Nx * Ny * nzv;
   const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +213,8 @@ k_pcg_classify(const T* __restrict__ diag, const T* __restrict__ cx, const T* __
       const int z = zv * VEC + j;
       if (z == 0 || z == Nz - 1) continue;                  // boundary cells are never computed: don't care
       const int64_t c = b + j;
-      const T k[7] = {diag[c], cx[c], cx[c + sx], cy[c], cy[c + Nz], cz[c], cz[c + 1]};
+      // symmetric operator: the -z weight is cz[c]; asymmetric: cz2[c] (cz[c] is then only cell c-1's +z weight)
+      const T k[7] = {diag[c], cx[c], cx[c + sx], cy[c], cy[c + Nz], cz2 ? cz2[c] : cz[c], cz[c + 1]};
       bool z0 = true, r1 = k[0] == (T)6;
 #pragma unroll
       for (int q = 0; q < 7; ++q) { z0 = z0 && k[q] == (T)0; if (q) r1 = r1 && k[q] == (T)1; }
@@ -257,13 +269,13 @@ struct VSrc {
 // PD = prefetch depth in planes for the operand vector and its halo rows (the long-latency streams):
 // their loads for plane x+1+PD are issued at step x and consumed PD steps later, which keeps PD
 // planes of v per wave in flight -- the march is latency-paced, so bytes in flight are what set its speed.
-template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD>
+template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD, bool ASYM = false>
 __global__ void __launch_bounds__(kApplyBlock, MFS_MARCH_MIN_WAVES)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
                   const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
                   const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
                   const double* __restrict__ done_flag, const T* __restrict__ fr, const T* __restrict__ fd_old,
-                  T* __restrict__ fd_new, const double* __restrict__ beta_ptr) {
+                  T* __restrict__ fd_new, const double* __restrict__ beta_ptr, const T* __restrict__ cz2) {
   static_assert(!FUSE || LDS, "the fused direction update is implemented on the LDS march");
   if (done_flag && *done_flag != 0.0) return;
   const VSrc<T, VEC, FUSE> src{v, fr, fd_old, FUSE ? *beta_ptr : 0.0};
@@ -321,7 +333,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       cls_c = cls[base / VEC];
       cls_n = cls[(base + (x0 + 1 < x1 ? sx : 0)) / VEC];
     }
-    CoefVec<T, VEC> cc = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, base, sx, Nz, cls_c);
+    CoefVec<T, VEC> cc = coef_load<T, VEC, COMP, NT, true, ASYM>(diag, cx, cy, cz, base, sx, Nz, cls_c, cz2);
     if (!COMP) cc.cxm = vload<T, VEC>(cx + base);
 
     if (LDS) {
@@ -366,7 +378,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
       const RawVec<T, VEC> qn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + m);   // operand vector, plane x+1+PD
       // plane x+1's coefficients (class known since the previous step); class of plane x+2
-      CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT, false>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls);
+      CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT, false, ASYM>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls, cz2);
       cn.cxm = cc.cxp;                                      // cx[x+1] was this step's upper-face weight
       unsigned char cls_nn = kClsMixed;
       if (COMP) cls_nn = cls[n2 / VEC];
@@ -391,7 +403,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const T czs = __shfl_down(cc.czm[0], 1, 64);
       const double czr = (double)((lane == 63 && !last) ? cz[base + VEC] : czs);
       stencil_vec<T, VEC>(out + base, vc, vp, vm, vyp, vym, cc.dg, cc.cxp, cc.cxm, cc.cyp, cc.cym, cc.czm, zl, zr, czr,
-                          first, last, active, acc);
+                          first, last, active, acc, cc.czm2);
       if (FUSE && active) vstore<T, VEC>(fd_new + base, vc);   // d_new of this vector (its z-boundary cells are 0 + beta*0)
       // ---- rotate; publish plane x+1 to the other LDS buffer
       if (more) {
@@ -418,162 +430,6 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       }
     }
     if (LDS) MFS_LDS_BARRIER();  // next work unit reuses buffer 0
-  }
-  const double tot = block_sum<kApplyBlock>(acc);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-// ------------------------------------------------------------- variant 3 ----
-// The LDS march with RY z-vectors per thread: the tile is RY*256 consecutive
-// vectors (thread t owns vectors t, t+256, ...), so a workgroup moves RY times the
-// bytes per plane step and per barrier, and the two halo rows are amortised over a
-// tile RY times as tall.  The march is latency-paced (one dependent memory round
-// trip per plane), so fatter steps are what converts spare bandwidth into speed.
-template <typename T, int VEC, int NT, bool COMP, int RY>
-__global__ void __launch_bounds__(kApplyBlock)
-k_pcg_apply_march_r(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
-                    const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
-                    const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
-                    const double* __restrict__ done_flag) {
-  if (done_flag && *done_flag != 0.0) return;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* const smem = reinterpret_cast<T*>(smem_raw);
-  constexpr int TILEV = RY * kApplyBlock;                   // z-vectors per tile
-  const int Nz = a.Nz;
-  const int nzv = Nz / VEC;
-  const int ipp = (a.Ny - 2) * nzv;
-  const int tiles = (ipp + TILEV - 1) / TILEV;
-  const int n1 = a.xe - a.xb;
-  const int np = n1 + (a.xe2 - a.xb2);
-  const int64_t total = (int64_t)tiles * np;                // (tile, plane) pairs, cut into gridDim equal segments
-  const int G = gridDim.x;
-  const int nch = min(G, kXcds);
-  const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
-  const int per = G / nch, extra = G - per * nch;
-  const int seg = xcd * per + min(xcd, extra) + slot;
-  const int64_t s0 = total * seg / G, s1 = total * (seg + 1) / G;
-  const int64_t sx = (int64_t)a.Ny * Nz;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int tile_elems = TILEV * VEC;
-  const int buf_elems = tile_elems + 2 * Nz;
-  const int hofs = tid * VEC;                               // halo slot owned by this thread (if < Nz)
-  double acc = 0.0;
-
-  for (int64_t i = s0; i < s1;) {
-    const int tile = (int)(i / np);
-    const int pl = (int)(i - (int64_t)tile * np);
-    const int x0 = pl < n1 ? a.xb + pl : a.xb2 + (pl - n1);
-    int len = (int)min((int64_t)((pl < n1 ? a.xe : a.xe2) - x0), s1 - i);
-    if (a.xchunk > 0) len = min(len, a.xchunk);
-    const int x1 = x0 + len;
-    i += len;
-    const int64_t m0 = (int64_t)Nz + (int64_t)tile * tile_elems;
-    const int tile_len = min(tile_elems, ipp * VEC - tile * tile_elems);
-
-    bool active[RY], first[RY], last[RY];
-    int64_t base[RY];
-    vec_t<T, VEC> vm[RY], vc[RY], vp[RY];
-    CoefVec<T, VEC> cc[RY];
-    unsigned char cls_n[RY];
-#pragma unroll
-    for (int r = 0; r < RY; ++r) {
-      const int item_raw = tile * TILEV + r * kApplyBlock + tid;
-      active[r] = item_raw < ipp;
-      const int item = active[r] ? item_raw : ipp - 1;
-      const int yy = item / nzv, zv = item - yy * nzv;
-      first[r] = zv == 0;
-      last[r] = zv == nzv - 1;
-      base[r] = (int64_t)x0 * sx + (int64_t)(yy + 1) * Nz + (int64_t)zv * VEC;
-      vm[r] = vload<T, VEC>(v + base[r] - sx);
-      vc[r] = vload<T, VEC>(v + base[r]);
-      vp[r] = vload<T, VEC>(v + base[r] + sx);
-      unsigned char c0 = kClsMixed;
-      cls_n[r] = kClsMixed;
-      if (COMP) {
-        c0 = cls[base[r] / VEC];
-        cls_n[r] = cls[(base[r] + (x0 + 1 < x1 ? sx : 0)) / VEC];
-      }
-      cc[r] = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, base[r], sx, Nz, c0);
-      if (!COMP) cc[r].cxm = vload<T, VEC>(cx + base[r]);
-    }
-    {  // stage plane x0 (tile + halos) into buffer 0
-      T* b0 = smem;
-#pragma unroll
-      for (int r = 0; r < RY; ++r)
-        if (active[r]) vstore<T, VEC>(b0 + Nz + (r * kApplyBlock + tid) * VEC, vc[r]);
-      for (int h = hofs; h < Nz; h += kApplyBlock * VEC) {
-        vstore<T, VEC>(b0 + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 - Nz + h));
-        vstore<T, VEC>(b0 + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)x0 * sx + m0 + tile_len + h));
-      }
-      MFS_LDS_BARRIER();
-    }
-    vec_t<T, VEC> hlo = {}, hhi = {};                       // halo vectors of plane x0+1
-    if (hofs < Nz) {
-      const int64_t hp = (int64_t)min(x0 + 1, x1) * sx + m0;
-      hlo = vload<T, VEC>(v + hp - Nz + hofs);
-      hhi = vload<T, VEC>(v + hp + tile_len + hofs);
-    }
-
-    for (int x = x0; x < x1; ++x) {
-      const bool more = x + 1 < x1;
-      const int cur = (x - x0) & 1;
-      // ---- prefetch (unconditional, clamped on the last step): plane x+2 of v, plane x+1's coefficients
-      vec_t<T, VEC> vpp[RY];
-      CoefVec<T, VEC> cn[RY];
-      unsigned char cls_nn[RY];
-#pragma unroll
-      for (int r = 0; r < RY; ++r) {
-        const int64_t nb = base[r] + sx;
-        const int64_t nn = more ? nb : base[r], n2 = more ? nb + sx : nb;
-        vpp[r] = vload<T, VEC>(v + n2);
-        cn[r] = coef_load<T, VEC, COMP, NT>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n[r] : cc[r].cls);
-        if (!COMP) cn[r].cxm = cc[r].cxp;
-        cls_nn[r] = kClsMixed;
-        if (COMP) cls_nn[r] = cls[n2 / VEC];
-      }
-      vec_t<T, VEC> hlo_n = {}, hhi_n = {};
-      if (hofs < Nz) {
-        const int64_t hp = (int64_t)(more ? x + 2 : x + 1) * sx + m0;
-        hlo_n = vload<T, VEC>(v + hp - Nz + hofs);
-        hhi_n = vload<T, VEC>(v + hp + tile_len + hofs);
-      }
-      // ---- plane x: in-plane neighbours from LDS, stencil, store
-      const T* bc = smem + cur * buf_elems;
-#pragma unroll
-      for (int r = 0; r < RY; ++r) {
-        const int lo = (r * kApplyBlock + tid) * VEC;        // this vector inside the tile
-        const vec_t<T, VEC> vym = vload<T, VEC>(bc + lo);
-        const vec_t<T, VEC> vyp = vload<T, VEC>(bc + 2 * Nz + lo);
-        const double zl = (double)bc[Nz + lo - 1], zr = (double)bc[Nz + lo + VEC];
-        const T czs = __shfl_down(cc[r].czm[0], 1, 64);
-        const double czr = (double)((lane == 63 && !last[r]) ? cz[base[r] + VEC] : czs);
-        stencil_vec<T, VEC>(out + base[r], vc[r], vp[r], vm[r], vyp, vym, cc[r].dg, cc[r].cxp, cc[r].cxm, cc[r].cyp,
-                            cc[r].cym, cc[r].czm, zl, zr, czr, first[r], last[r], active[r], acc);
-      }
-      // ---- rotate; publish plane x+1 to the other LDS buffer
-      if (more) {
-        T* bn = smem + (cur ^ 1) * buf_elems;
-#pragma unroll
-        for (int r = 0; r < RY; ++r)
-          if (active[r]) vstore<T, VEC>(bn + Nz + (r * kApplyBlock + tid) * VEC, vp[r]);
-        if (hofs < Nz) {
-          vstore<T, VEC>(bn + hofs, hlo);
-          vstore<T, VEC>(bn + Nz + tile_len + hofs, hhi);
-        }
-        for (int h = hofs + kApplyBlock * VEC; h < Nz; h += kApplyBlock * VEC) {   // rows longer than 256 vectors
-          vstore<T, VEC>(bn + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 - Nz + h));
-          vstore<T, VEC>(bn + Nz + tile_len + h, vload<T, VEC>(v + (int64_t)(x + 1) * sx + m0 + tile_len + h));
-        }
-        MFS_LDS_BARRIER();
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-          vm[r] = vc[r]; vc[r] = vp[r]; vp[r] = vpp[r]; cc[r] = cn[r]; cls_n[r] = cls_nn[r];
-          base[r] += sx;
-        }
-        hlo = hlo_n; hhi = hhi_n;
-      }
-    }
-    MFS_LDS_BARRIER();   // next work unit reuses buffer 0
   }
   const double tot = block_sum<kApplyBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;

@@ -111,7 +111,7 @@ k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     stencil_vec<T, VEC>(out + base, vc, vxp, vxm, vload<T, VEC>(v + base + sy), vload<T, VEC>(v + base - sy),
                         vload<T, VEC>(diag + base), vload<T, VEC>(cx + base + sx), vload<T, VEC>(cx + base),
                         vload<T, VEC>(cy + base + sy), vload<T, VEC>(cy + base), vload<T, VEC>(cz + base), zl, zr, czr,
-                        first, last, true, acc);
+                        first, last, true, acc, vload<T, VEC>(cz + base));
   }
   if (lost) slab_fail(scal, 2);
   const double tot = block_sum<kApplyBlock>(acc);

@@ -103,6 +103,13 @@ SIGNATURES = {
     "mfs_vcg3d_history": (_i64, [_p, _pd, _i64, _p]),
     "mfs_grid_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "mfs_grid_boundary_condition3d": (_i, [_pi64, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _d, _p, _p, _p, _i, _p]),
+    "mfs_pcg3d_setup_density": (_i, [_p, _p, _i, _p, _p, _p, _i, _p]),
+    "mfs_density_splat3d": (_i, [_pi64, _pd, _pd, _p, _i, _p, _i, _d, _i64, _p, _p, _i, _p]),
+    "mfs_density_fix_volume3d": (_i, [_pi64, _pd, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),
+    "mfs_density_rhs3d": (_i, [_pi64, _d, _d, _pd, _p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _p]),
+    "mfs_density_apply3d": (_i, [_pi64, _p, _p, _i, _p, _p, _p, _i, _p, _i, _p]),
+    "mfs_density_displacement3d": (_i, [_pi64, _d, _pd, _p, _p, _p, _i, _p, _i, _p, _i, _p]),
+    "mfs_density_advect3d": (_i, [_p, _i, _i64, _p, _i, _pi64, _pd, _pd, _pd, _i, _p]),
     "mfs_pressure_rhs2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "mfs_pressure_apply2d": (_i, [_pi64, _p, _p, _i, _p, _p, _i, _p, _i, _p]),
     "mfs_pressure_update2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p]),

@@ -65,6 +65,16 @@ class PcgEngine:
         _lib.check(self.lib.mfs_pcg3d_setup(self.h, T.ptr(lphi), T.code(lphi), T.ptr(wx), T.ptr(wy), T.ptr(wz),
                                             T.code(wx), T.stream()), "mfs_pcg3d_setup")
 
+    def setup_density(self, lphi, wx, wy, wz):
+        """the density solver's operator (solver/DensityCGSolver3D.py:118-207) instead of the pressure one"""
+        g = self.gres
+        lphi = T.dev(lphi, "lphi", g)
+        wx, wy, wz = (T.dev(w, n, T.face_shape(g, a)) for a, (w, n) in enumerate(((wx, "wx"), (wy, "wy"), (wz, "wz"))))
+        if not (wx.dtype == wy.dtype == wz.dtype):
+            raise TypeError("wx, wy, wz must share a dtype")
+        _lib.check(self.lib.mfs_pcg3d_setup_density(self.h, T.ptr(lphi), T.code(lphi), T.ptr(wx), T.ptr(wy), T.ptr(wz),
+                                                    T.code(wx), T.stream()), "mfs_pcg3d_setup_density")
+
     def bind(self, b, x, d, r, q):
         ts = [T.dev(a, n, self.gres) for a, n in ((b, "b"), (x, "x"), (d, "d"), (r, "r"), (q, "q"))]
         for t in ts:

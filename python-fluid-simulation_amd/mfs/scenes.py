@@ -312,3 +312,29 @@ def viscosity_scene_3d(gres, seed=3, *, bound_size=(1.0, 1.0, 1.0), vel_dtype=np
             n = torch.randn(arr.shape, generator=g, device=device, dtype=torch.float64)
             out[name] = (arr + noise * n * m).to(tdt)
     return out
+
+
+def density_scene_3d(gres, seed=0, *, per_cell=4, bound_min=(-0.25, 0.1, 0.0), px_dtype=np.float64, rho0=1000.0,
+                     dt=1.0 / 300.0):
+    """Inputs of DensityCGSolver3D.solve: the pool scene of `pressure_scene_3d`
+    (shifted by `bound_min`) filled with jittered particles below the free surface; particle masses
+    rho0 * pvol * (1 +- 10 %), so the density right-hand side is non-trivial.  numpy only."""
+    sc = pressure_scene_3d(gres, seed)
+    Nx, Ny, Nz = (int(g) for g in gres)
+    size = np.asarray(sc["bound_size"], np.float64)
+    cs = size / np.array([Nx, Ny, Nz], np.float64)
+    rng = np.random.default_rng(seed + 1000)
+    n = per_cell * Nx * Ny * Nz
+    pos = rng.uniform(0.6 * cs, size - 0.6 * cs, size=(n, 3))
+    ci = np.minimum((pos / cs).astype(np.int64), np.array([Nx - 1, Ny - 1, Nz - 1]))
+    lphi = np.asarray(sc["lphi"])
+    sphi_c = np.asarray(sc["sphi"])[1::2, 1::2, 1::2]
+    keep = (lphi[ci[:, 0], ci[:, 1], ci[:, 2]] < 0) & (sphi_c[ci[:, 0], ci[:, 1], ci[:, 2]] > 0)
+    pos = pos[keep]
+    pvol = float(np.prod(cs)) / per_cell
+    pm = rho0 * pvol * (1.0 + 0.1 * rng.standard_normal(len(pos)))
+    px = (pos + np.asarray(bound_min, np.float64)).astype(px_dtype)
+    lvol = np.zeros_like(np.asarray(sc["sphi"]))        # accepted and unused by the density solver (:262-269)
+    return dict(gres=(Nx, Ny, Nz), bound_min=tuple(float(b) for b in bound_min), bound_size=tuple(float(v) for v in size),
+                sphi=sc["sphi"], sv=sc["sv"], lphi=sc["lphi"], lvol=lvol, px=px, pm=pm, pvol=pvol, rho0=float(rho0),
+                dt=float(dt))

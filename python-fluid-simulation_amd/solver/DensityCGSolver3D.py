@@ -1,0 +1,173 @@
+"""Drop-in for the reference's solver/DensityCGSolver3D.py on MI355X.
+
+Same module functions, class, constructor and `solve` signature as the reference
+(file:line cited per item), on PyTorch-ROCm tensors, calling the HIP kernels of
+libmfs_hip.so through the C ABI (include/mfs.h).  The CG loop runs on the pressure
+engine set up for the density operator (csrc/mfs_pcg.hip, mfs_pcg3d_setup_density):
+device-resident scalars, no host sync per iteration.  No CPU path.
+"""
+import numpy as np
+import torch
+
+from mfs import _lib, tensors as T
+from mfs.pcg import PcgEngine
+from .SolidFraction3D import compute_solid_frac, edge_in_fraction  # noqa: F401  (reference line 6)
+
+
+def _faces(g, wx, wy, wz, names=("wx", "wy", "wz")):
+    wx = T.dev(wx, names[0], T.face_shape(g, 0))
+    wy = T.dev(wy, names[1], T.face_shape(g, 1))
+    wz = T.dev(wz, names[2], T.face_shape(g, 2))
+    if not (wx.dtype == wy.dtype == wz.dtype):
+        raise TypeError(f"{', '.join(names)} must share a dtype")
+    return wx, wy, wz
+
+
+def _particles(px):
+    px = T.dev(px, "px")
+    if px.dim() != 2 or px.shape[1] != 3:
+        raise ValueError(f"px: expected shape (P, 3), got {tuple(px.shape)}")
+    return px
+
+
+def initialize_density(bound_min, cell_size, gres, px, pm, pvol, gm, gvol, sphi=None, lphi=None):
+    """Scatter particle mass / volume to the cell centres (reference :255-260 -> kernel :8-36).
+    `sphi`, `lphi` are accepted and unused, as in the reference."""
+    g = T.as_gres(gres)
+    px = _particles(px)
+    pm = T.dev(pm, "pm", (px.shape[0],))
+    gm, gvol = T.dev(gm, "gm", g), T.dev(gvol, "gvol", g)
+    if gm.dtype != gvol.dtype:
+        raise TypeError("gm and gvol must share a dtype")
+    lib = _lib.load()
+    _lib.check(lib.mfs_density_splat3d(_lib.i64x(g), _lib.f64x(T.as_f64_list(bound_min, 3)),
+                                       _lib.f64x(T.as_f64_list(cell_size, 3)), T.ptr(px), T.code(px), T.ptr(pm),
+                                       T.code(pm), float(pvol), int(px.shape[0]), T.ptr(gm), T.ptr(gvol), T.code(gm),
+                                       T.stream()), "mfs_density_splat3d")
+
+
+def fix_volume(cell_size, gres, lvol, gvol, sphi, lphi, wx, wy, wz):
+    """Clamp the splatted cell volume (reference :262-269 -> kernel :38-86); `lvol` is unused there."""
+    g = T.as_gres(gres)
+    gvol = T.dev(gvol, "gvol", g)
+    sphi = T.dev(sphi, "sphi", T.doubled_shape(g))
+    lphi = T.dev(lphi, "lphi", g)
+    wx, wy, wz = _faces(g, wx, wy, wz)
+    lib = _lib.load()
+    _lib.check(lib.mfs_density_fix_volume3d(_lib.i64x(g), _lib.f64x(T.as_f64_list(cell_size, 3)), T.ptr(gvol),
+                                            T.code(gvol), T.ptr(sphi), T.code(sphi), T.ptr(lphi), T.code(lphi),
+                                            T.ptr(wx), T.ptr(wy), T.ptr(wz), T.code(wx), T.stream()),
+               "mfs_density_fix_volume3d")
+
+
+def initialize_solver(rho0, dt, gres, cell_size, gm, gvol, lphi, wx, wy, wz, b):
+    """Right-hand side (reference :271-277 -> kernel :88-116)."""
+    g = T.as_gres(gres)
+    gm, gvol = T.dev(gm, "gm", g), T.dev(gvol, "gvol", g)
+    if gm.dtype != gvol.dtype:
+        raise TypeError("gm and gvol must share a dtype")
+    lphi = T.dev(lphi, "lphi", g)
+    wx, wy, wz = _faces(g, wx, wy, wz)
+    b = T.dev(b, "b", g)
+    lib = _lib.load()
+    _lib.check(lib.mfs_density_rhs3d(_lib.i64x(g), float(rho0), float(dt), _lib.f64x(T.as_f64_list(cell_size, 3)),
+                                     T.ptr(gm), T.ptr(gvol), T.code(gm), T.ptr(lphi), T.code(lphi), T.ptr(wx),
+                                     T.ptr(wy), T.ptr(wz), T.code(wx), T.ptr(b), T.code(b), T.stream()),
+               "mfs_density_rhs3d")
+
+
+def matvecmul(gres, v, out, wx, wy, wz, lphi):
+    """out = A v, the density solver's operator (reference :279-283 -> kernel :118-207)."""
+    g = T.as_gres(gres)
+    v, out = T.dev(v, "v", g), T.dev(out, "out", g)
+    if v.dtype != out.dtype:
+        raise TypeError("v and out must share a dtype")
+    wx, wy, wz = _faces(g, wx, wy, wz)
+    lphi = T.dev(lphi, "lphi", g)
+    lib = _lib.load()
+    _lib.check(lib.mfs_density_apply3d(_lib.i64x(g), T.ptr(v), T.ptr(out), T.code(v), T.ptr(wx), T.ptr(wy), T.ptr(wz),
+                                       T.code(wx), T.ptr(lphi), T.code(lphi), T.stream()), "mfs_density_apply3d")
+
+
+def compute_displacement(gres, dt, cell_size, dx, dy, dz, pv, lphi):
+    """Face displacements from the solved field (reference :285-289 -> kernel :209-222)."""
+    g = T.as_gres(gres)
+    dx, dy, dz = _faces(g, dx, dy, dz, ("dx", "dy", "dz"))
+    pv, lphi = T.dev(pv, "pv", g), T.dev(lphi, "lphi", g)
+    lib = _lib.load()
+    _lib.check(lib.mfs_density_displacement3d(_lib.i64x(g), float(dt), _lib.f64x(T.as_f64_list(cell_size, 3)),
+                                              T.ptr(dx), T.ptr(dy), T.ptr(dz), T.code(dx), T.ptr(pv), T.code(pv),
+                                              T.ptr(lphi), T.code(lphi), T.stream()), "mfs_density_displacement3d")
+
+
+def apply_displacement(px, dx, bound_min, cell_size, grid_bias, axis):
+    """px[:, axis] += trilinear sample of the face array (reference :291-296 -> kernel :224-253)."""
+    px = _particles(px)
+    dx = T.dev(dx, "dx")
+    if dx.dim() != 3:
+        raise ValueError("dx: expected a 3D face array")
+    lib = _lib.load()
+    _lib.check(lib.mfs_density_advect3d(T.ptr(px), T.code(px), int(px.shape[0]), T.ptr(dx), T.code(dx),
+                                        _lib.i64x(tuple(dx.shape)), _lib.f64x(T.as_f64_list(bound_min, 3)),
+                                        _lib.f64x(T.as_f64_list(cell_size, 3)), _lib.f64x(T.as_f64_list(grid_bias, 3)),
+                                        int(axis), T.stream()), "mfs_density_advect3d")
+
+
+class DensityCGSolver3D:
+    """Reference :298-350.  `DensityCGSolver3D(buf, gres, bound_min, bound_size)`; shares the
+    `CGSolverBuffer` with the pressure solver like the reference does (ipynb:777-779).
+    `self.wx, self.wy, self.wz` are what the notebook hands to the pressure solve (ipynb:4648).
+    Extras that do not change reference behaviour: `iterations`, `history`, `check_every`."""
+
+    def __init__(self, buf, gres, bound_min, bound_size, check_every=32):
+        self.gres = gres
+        self._g = T.as_gres(gres)
+        if len(self._g) != 3:
+            raise ValueError("DensityCGSolver3D needs a 3D grid")
+        self.bound_min = np.array(T.as_f64_list(bound_min, 3))
+        self.cell_size = np.array(T.as_f64_list(bound_size, 3)) / np.array(self._g, dtype=np.float64)
+        self.bias_x = np.array([0, 0.5, 0.5])
+        self.bias_y = np.array([0.5, 0, 0.5])
+        self.bias_z = np.array([0.5, 0.5, 0])
+        self.buf = buf
+        dt, device = buf.b.dtype, buf.b.device
+        z = lambda shape: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
+        self.m, self.vol, self.x = z(self._g), z(self._g), z(self._g)
+        self.wx, self.wy, self.wz = (z(T.face_shape(self._g, a)) for a in range(3))
+        self.dx, self.dy, self.dz = (z(T.face_shape(self._g, a)) for a in range(3))
+        self.alpha = 0.0
+        self.beta = 0.0
+        self.delta = 0.0
+        self.max_iter = int(np.prod(self._g))
+        self.check_every = int(check_every)
+        self.iterations = 0
+        self._engine = PcgEngine(self._g, dt, device)
+
+    @property
+    def history(self):
+        return self._engine.history()
+
+    def solve(self, rho0, dt, px, pm, pvol, vx, vy, vz, sphi, sv, lphi, lvol, wx=None, wy=None, wz=None, tol=1e-3):
+        g = self._g
+        if wx is None or wy is None or wz is None:
+            compute_solid_frac(self.gres, sphi, self.wx, self.wy, self.wz)
+            wx, wy, wz = self.wx, self.wy, self.wz
+        eng = self._engine
+        with torch.cuda.device(self.x.device):
+            self.m *= 0
+            self.vol *= 0
+            initialize_density(self.bound_min, self.cell_size, g, px, pm, pvol, self.m, self.vol, sphi, lphi)
+            fix_volume(self.cell_size, g, lvol, self.vol, sphi, lphi, wx, wy, wz)
+            initialize_solver(rho0, dt, g, self.cell_size, self.m, self.vol, lphi, wx, wy, wz, self.buf.b)
+            eng.setup_density(lphi, wx, wy, wz)
+            eng.bind(self.buf.b, self.x, self.buf.d, self.buf.r, self.buf.q)
+            ok, self.iterations = eng.solve(tol, self.max_iter, self.check_every)     # x *= 0 happens inside (:320)
+            st = eng.poll()
+            self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
+            if not ok:
+                raise ValueError("Failed to converge!")
+            # self.x : -pressure * dt / rho / dx^2
+            compute_displacement(g, dt, self.cell_size, self.dx, self.dy, self.dz, self.x, lphi)
+            apply_displacement(px, self.dx, self.bound_min, self.cell_size, self.bias_x, 0)
+            apply_displacement(px, self.dy, self.bound_min, self.cell_size, self.bias_y, 1)
+            apply_displacement(px, self.dz, self.bound_min, self.cell_size, self.bias_z, 2)

@@ -8,7 +8,7 @@ container-only plumbing in tests/golden/refshim/ (numpy as the array container,
 a sequential per-thread launcher) ahead of /root/reference on sys.path and then
 imports `solver.PressureCGSolver3D`, `solver.ViscosityCGSolver3D`,
 `solver.PressureCGSolver2D`, `solver.SolidFraction{2D,3D}`,
-`solver.CGSolverBuffer` UNMODIFIED and calls their public functions / classes.
+`solver.CGSolverBuffer`, `solver.DensityCGSolver3D` UNMODIFIED and calls their public functions / classes.
 Every arithmetic statement that produces a fixture is the reference's.
 
 What this does NOT pin: cupy/numba-CUDA execution itself (FMA contraction and
@@ -46,6 +46,7 @@ import solver.SolidFraction2D as RS2        # noqa: E402
 import solver.SolidFraction3D as RS3        # noqa: E402
 import solver.SolidFractionCommon as RSC    # noqa: E402
 import solver.ViscosityCGSolver3D as RV3    # noqa: E402
+import solver.DensityCGSolver3D as RD3      # noqa: E402
 
 assert RP3.__file__.startswith(REF), RP3.__file__
 
@@ -210,6 +211,55 @@ def gen_viscosity3d(name, gres, seed, vel_dtype, tol=1e-3, mu=None):
         out_vx=np.asarray(vx), out_vy=np.asarray(vy), out_vz=np.asarray(vz))
 
 
+def gen_density3d(name, gres, seed, per_cell=4, tol=1e-3, px_dtype=np.float64):
+    """solver/DensityCGSolver3D.py: the module functions one by one, then the class end to end."""
+    sc = scenes.density_scene_3d(gres, seed, per_cell=per_cell, px_dtype=px_dtype)
+    g = C(gres, np.int64)
+    bmin, bsz = C(sc["bound_min"], np.float64), C(sc["bound_size"], np.float64)
+    sphi, sv, lphi, lvol = C(sc["sphi"]), C(sc["sv"]), C(sc["lphi"]), C(sc["lvol"])
+    cell_size = bsz / g
+    wx = cp.zeros((gres[0] + 1, gres[1], gres[2]))
+    wy = cp.zeros((gres[0], gres[1] + 1, gres[2]))
+    wz = cp.zeros((gres[0], gres[1], gres[2] + 1))
+    RS3.compute_solid_frac(g, sphi, wx, wy, wz)
+    gm, gvol = cp.zeros(gres), cp.zeros(gres)
+    RD3.initialize_density(bmin, cell_size, g, C(sc["px"]), C(sc["pm"]), sc["pvol"], gm, gvol, sphi, lphi)
+    gvol_raw = np.array(gvol)
+    RD3.fix_volume(cell_size, g, lvol, gvol, sphi, lphi, wx, wy, wz)
+    b = cp.zeros(gres)
+    RD3.initialize_solver(sc["rho0"], sc["dt"], g, cell_size, gm, gvol, lphi, wx, wy, wz, b)
+    q1 = cp.zeros(gres)
+    RD3.matvecmul(g, b, q1, wx, wy, wz, lphi)
+    rv = np.random.default_rng(seed + 100).standard_normal(gres)
+    qr = cp.array(np.full(gres, 7.0))          # sentinel: boundary cells must stay 7
+    RD3.matvecmul(g, C(rv), qr, wx, wy, wz, lphi)
+
+    buf = RB.CGSolverBuffer(g)
+    slv = RD3.DensityCGSolver3D(buf, g, bmin, bsz)
+    px = C(sc["px"])
+    logger = _SumLogger(cp)
+    RD3.cp = logger
+    t0 = time.time()
+    try:
+        slv.solve(sc["rho0"], sc["dt"], px, C(sc["pm"]), sc["pvol"], None, None, None, sphi, sv, lphi, lvol, tol=tol)
+    finally:
+        RD3.cp = cp
+    hist = np.array(logger.log)
+    iters = (len(hist) - 1) // 2
+    print(f"  {name}: gres={gres} particles={len(sc['px'])} iters={iters} delta0={hist[0]:.4e} delta_end={hist[-1]:.4e}"
+          f" ({time.time() - t0:.1f}s)")
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        kind="density3d", gres=np.array(gres), bound_min=np.array(sc["bound_min"]), bound_size=np.array(sc["bound_size"]),
+        tol=tol, seed=seed, rho0=sc["rho0"], dt=sc["dt"], pvol=sc["pvol"],
+        px=sc["px"], pm=sc["pm"], sphi=sc["sphi"], sv=sc["sv"], lphi=sc["lphi"], lvol=sc["lvol"],
+        wx=np.asarray(wx), wy=np.asarray(wy), wz=np.asarray(wz), gm=np.asarray(gm), gvol_raw=gvol_raw,
+        gvol=np.asarray(gvol), b=np.asarray(b), q1=np.asarray(q1), rv=rv, qr=np.asarray(qr),
+        history=hist, iters=iters, x=np.asarray(slv.x), dx=np.asarray(slv.dx), dy=np.asarray(slv.dy),
+        dz=np.asarray(slv.dz), out_px=np.asarray(px), out_gm=np.asarray(slv.m), out_gvol=np.asarray(slv.vol),
+        alpha=slv.alpha, beta=slv.beta, delta=slv.delta)
+
+
 def gen_fraction_tables(name):
     """Known-answer tables of the three device functions in
     solver/SolidFractionCommon.py, evaluated on a grid of sign patterns."""
@@ -236,6 +286,8 @@ CASES = [
     ("v3d_a_12", lambda n: gen_viscosity3d(n, (12, 12, 12), 3, np.float32)),
     ("v3d_b_10x12x14", lambda n: gen_viscosity3d(n, (10, 12, 14), 4, np.float64)),
     ("v3d_c_16_mu50", lambda n: gen_viscosity3d(n, (16, 16, 16), 5, np.float32, mu=50.0)),
+    ("d3d_a_12", lambda n: gen_density3d(n, (12, 12, 12), 9)),
+    ("d3d_b_10x12x14_f32", lambda n: gen_density3d(n, (10, 12, 14), 10, per_cell=3, px_dtype=np.float32)),
 ]
 
 if __name__ == "__main__":

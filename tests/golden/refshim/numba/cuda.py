@@ -8,7 +8,7 @@ arithmetic statement executed is the reference's own source
 (SURVEY.md section 8(c), Appendix B).  It contains no solver arithmetic.
 
 Supported surface = exactly what the hot-path files touch:
-`jit` (bare and `device=True`), `grid(2|3)`, `local.array`, `synchronize`.
+`jit` (bare and `device=True`), `grid(1|2|3)`, `local.array`, `atomic.add/min`, `synchronize`.
 """
 import itertools
 
@@ -70,6 +70,26 @@ class _Local:
 
 
 local = _Local()
+
+
+class _Atomic:
+    """cuda.atomic.add / min on a sequential launcher: a plain read-modify-write."""
+
+    @staticmethod
+    def add(arr, idx, val):
+        old = arr[idx]
+        arr[idx] = old + val
+        return old
+
+    @staticmethod
+    def min(arr, idx, val):
+        old = arr[idx]
+        if val < old:
+            arr[idx] = val
+        return old
+
+
+atomic = _Atomic()
 
 
 def synchronize():
