@@ -20,6 +20,9 @@
 //    per cell, vs 8x-strided reads of two (2N+1)^3 arrays in the reference.
 #include "mfs_cg_core.h"
 
+// workgroup barrier that waits on LDS traffic only: the global prefetch of the next plane stays in flight
+#define MFS_VISC_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 namespace mfs {
 
 struct VTap { int fac, vol, sgn, comp, dx, dy, dz, mx, my, mz; };
@@ -262,27 +265,25 @@ struct Vec3T { const T* p[3]; };
 
 struct Box3 { int lo[3], hi[3]; };   // face-index box [lo, hi) of one row
 
-// One operator row at face (x,y,z) on the compact arrays.  All loads are
-// unconditional (no load depends on a mask value), so the ~40 loads of a face are
-// in flight together.  MASK=false drops the tap masks: in the CG the operand is
-// `d`, which is exactly 0 on solid and array-boundary faces, so they cannot matter;
-// the initial q = A x (x = extrapolated velocity, non-zero on solid faces) and the
-// stand-alone apply use MASK=true.  The row's OWN mask (solid face -> out = 0) always applies.
-template <typename T, int AXIS, bool MASK>
-__device__ __forceinline__ double vcg_row(const Compact& c, double k1, double k2, const Vec3T<T>& v, int x, int y,
-                                          int z, double& own_out) {
-  const int s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
-  const int64_t f = ((int64_t)x * s1 + y) * s2 + z;
+// One operator row at face (x,y,z) on the compact arrays, written against a SAMPLER that hands out the
+// row's operands: S::vol(p, ox, oy, oz) = volume class p at compact index (x+ox, y+oy, z+oz),
+// S::vel(comp, dx, dy, dz) = velocity component at face (x+dx, y+dy, z+dz), S::tap_ok(...) = validity of
+// that face.  The global sampler reads the arrays directly (every load unconditional, so the ~40 loads of
+// a face are in flight together); the LDS sampler of the tiled kernel reads the staged plane tiles.
+// MASK=false drops the tap masks: in the CG the operand is `d`, which is exactly 0 on solid and
+// array-boundary faces, so they cannot matter; the initial q = A x (x = extrapolated velocity, non-zero
+// on solid faces) and the stand-alone apply use MASK=true.  The row's OWN mask (solid face -> out = 0)
+// always applies.
+template <int AXIS, bool MASK, typename S>
+__device__ __forceinline__ double vcg_row_s(const S& smp, double k1, double k2, bool own_ok, double& own_out) {
   double vs[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     const int ax = kD0[AXIS][0] + kVolOff[k][0], ay = kD0[AXIS][1] + kVolOff[k][1], az = kD0[AXIS][2] + kVolOff[k][2];
     const int p = ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1);
-    const int e1 = c.N[1] + ((ay & 1) ? 0 : 1), e2 = c.N[2] + ((az & 1) ? 0 : 1);
-    vs[k] = (double)((const T*)c.vol[p])[((int64_t)(x + fdiv2(ax)) * e1 + (y + fdiv2(ay))) * e2 + (z + fdiv2(az))];
+    vs[k] = smp.vol(p, fdiv2(ax), fdiv2(ay), fdiv2(az));
   }
-  const double own = (double)v.p[AXIS][f];
-  const bool own_ok = c.msk[face_class(AXIS)][f] != 0;
+  const double own = smp.vel(AXIS, 0, 0, 0);
   double s = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -293,15 +294,42 @@ __device__ __forceinline__ double vcg_row(const Compact& c, double k1, double k2
 #pragma unroll
   for (int t = 0; t < 14; ++t) {
     const VTap tp = kTaps[AXIS][t];
-    const int cs1 = c.N[1] + (tp.comp == 1), cs2 = c.N[2] + (tp.comp == 2);
-    const int64_t nb = ((int64_t)(x + tp.dx) * cs1 + (y + tp.dy)) * cs2 + (z + tp.dz);
-    double nbv = (double)v.p[tp.comp][nb];
+    double nbv = smp.vel(tp.comp, tp.dx, tp.dy, tp.dz);
     // the tap's mask sample is the validity of the tapped face itself (see header)
-    if (MASK) nbv = c.msk[face_class(tp.comp)][nb] ? nbv : 0.0;
+    if (MASK) nbv = smp.tap_ok(tp.comp, tp.dx, tp.dy, tp.dz) ? nbv : 0.0;
     val += tp.sgn * ((tp.fac == 2 ? k2 : k1) * vs[tp.vol] * nbv);
   }
   own_out = own;
   return own_ok ? val : 0.0;
+}
+
+template <typename T>
+struct GlobalSampler {
+  const Compact& c;
+  const Vec3T<T>& v;
+  int x, y, z;
+  __device__ __forceinline__ double vol(int p, int ox, int oy, int oz) const {
+    const int e1 = c.N[1] + ((p & 2) ? 0 : 1), e2 = c.N[2] + ((p & 1) ? 0 : 1);
+    return (double)((const T*)c.vol[p])[((int64_t)(x + ox) * e1 + (y + oy)) * e2 + (z + oz)];
+  }
+  __device__ __forceinline__ int64_t fidx(int comp, int dx, int dy, int dz) const {
+    const int cs1 = c.N[1] + (comp == 1), cs2 = c.N[2] + (comp == 2);
+    return ((int64_t)(x + dx) * cs1 + (y + dy)) * cs2 + (z + dz);
+  }
+  __device__ __forceinline__ double vel(int comp, int dx, int dy, int dz) const {
+    return (double)v.p[comp][fidx(comp, dx, dy, dz)];
+  }
+  __device__ __forceinline__ bool tap_ok(int comp, int dx, int dy, int dz) const {
+    return c.msk[face_class(comp)][fidx(comp, dx, dy, dz)] != 0;
+  }
+};
+
+template <typename T, int AXIS, bool MASK>
+__device__ __forceinline__ double vcg_row(const Compact& c, double k1, double k2, const Vec3T<T>& v, int x, int y,
+                                          int z, double& own_out) {
+  const GlobalSampler<T> smp{c, v, x, y, z};
+  const bool own_ok = c.msk[face_class(AXIS)][smp.fidx(AXIS, 0, 0, 0)] != 0;
+  return vcg_row_s<AXIS, MASK>(smp, k1, k2, own_ok, own_out);
 }
 
 // rows of ONE component over a box of faces (used for the three boundary slabs the
@@ -328,6 +356,53 @@ k_vcg_apply_row(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ out
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// the three boundary slabs (u at x = Nx-1, v at y = Ny-1, w at z = Nz-1) in ONE launch: blocks [0, g0) take
+// the first box, [g0, g0+g1) the second, the rest the third (one launch instead of three per iteration)
+template <typename T, int AXIS, bool MASK>
+__device__ __forceinline__ double vcg_slab_rows(const Compact& c, double k1, double k2, const Vec3T<T>& v,
+                                                T* __restrict__ out, const Box3& bx, int blk, int nblk) {
+  const int s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
+  const int i0 = bx.hi[0] - bx.lo[0], i1 = bx.hi[1] - bx.lo[1], i2 = bx.hi[2] - bx.lo[2];
+  const int64_t nint = (int64_t)i0 * i1 * i2;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
+  double acc = 0.0;
+  for (int64_t it = (int64_t)blk * blockDim.x + threadIdx.x; it < nint; it += stride) {
+    const int z = bx.lo[2] + (int)(it % i2), y = bx.lo[1] + (int)((it / i2) % i1), x = bx.lo[0] + (int)(it / ((int64_t)i2 * i1));
+    double own;
+    const double val = vcg_row<T, AXIS, MASK>(c, k1, k2, v, x, y, z, own);
+    const T o = (T)val;
+    out[((int64_t)x * s1 + y) * s2 + z] = o;
+    acc += own * (double)o;
+  }
+  return acc;
+}
+
+template <typename T, bool MASK>
+__global__ void __launch_bounds__(256)
+k_vcg_apply_slabs(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
+                  Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
+                  const double* __restrict__ done_flag) {
+  if (done_flag && *done_flag != 0.0) return;
+  const int b = blockIdx.x, g2 = gridDim.x - g0 - g1;
+  double acc;
+  if (b < g0) acc = vcg_slab_rows<T, 0, MASK>(c, k1, k2, v, ox, b0, b, g0);
+  else if (b < g0 + g1) acc = vcg_slab_rows<T, 1, MASK>(c, k1, k2, v, oy, b1, b - g0, g1);
+  else acc = vcg_slab_rows<T, 2, MASK>(c, k1, k2, v, oz, b2, b - g0 - g1, g2);
+  const double tot = block_sum<256>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and
+// its L2), so neighbouring tiles -- which read each other's halo rows -- would sit on different L2s and every
+// halo line would be fetched from HBM twice.  Give each XCD a CONTIGUOUS range of logical tile ids instead.
+__device__ __forceinline__ int xcd_logical_block(int on) {
+  if (!on) return blockIdx.x;
+  const int G = gridDim.x, nch = min(G, 8);
+  const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
+  const int per = G / nch, extra = G - per * nch;           // the first `extra` XCDs own one more block
+  return xcd * per + min(xcd, extra) + slot;
+}
+
 // The per-iteration kernel: all three rows of cell (x,y,z) by one thread, over the
 // box x in [1,Nx-2], y in [1,Ny-2], z in [1,Nz-2] where every row is an interior
 // face.  The three rows share most of their operands (27 distinct velocity and 16
@@ -338,11 +413,12 @@ k_vcg_apply_row(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ out
 template <typename T, bool MASK>
 __global__ void __launch_bounds__(256)
 k_vcg_apply_fused(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy,
-                  T* __restrict__ oz, int xchunk, int nbz, int nby, double* __restrict__ partial,
+                  T* __restrict__ oz, int xchunk, int nbz, int nby, int xcd_order, double* __restrict__ partial,
                   const double* __restrict__ done_flag) {
   if (done_flag && *done_flag != 0.0) return;
   const int Nx = c.N[0], Ny = c.N[1], Nz = c.N[2];
-  const int bz = blockIdx.x % nbz, by = (blockIdx.x / nbz) % nby, bxk = blockIdx.x / (nbz * nby);
+  const int lb = xcd_logical_block(xcd_order);
+  const int bz = lb % nbz, by = (lb / nbz) % nby, bxk = lb / (nbz * nby);
   const int zr = 1 + bz * 64 + (threadIdx.x & 63), yr = 1 + by * 4 + (threadIdx.x >> 6);
   const bool active = zr <= Nz - 2 && yr <= Ny - 2;
   const int z = min(zr, Nz - 2), y = min(yr, Ny - 2);      // inactive lanes recompute a valid cell, store nothing
@@ -365,6 +441,130 @@ k_vcg_apply_fused(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// The per-iteration kernel, LDS-staged: a workgroup owns a TY x TZ tile of cells and marches over a
+// chunk of x planes.  The ten operand arrays of the operator (3 velocity components, 7 volume classes)
+// are staged plane by plane into LDS as (TY+2) x (TZ+2) tiles -- one ring of three planes (x-1, x, x+1)
+// per array -- with coalesced row-segment loads issued one plane ahead into registers; every one of the
+// 43 samples a cell's three rows need is then an LDS read at a constant offset.  Global traffic per cell
+// drops from 43 L2-served loads (the vector L1 cannot hold the working set of 12 waves) to the 10 streams
+// plus halo.  Arithmetic, operand order and results are those of k_vcg_apply_fused (same vcg_row_s).
+template <typename T, int TY, int TZ>
+struct VTile {
+  static constexpr int PY = TY + 2, PZ = TZ + 2, PLANE = PY * PZ, NARR = 10, BLOCK = TY * TZ;
+  static constexpr int NSTG = (PLANE + BLOCK - 1) / BLOCK;          // staging elements per thread per array
+  static constexpr size_t lds_bytes() { return (size_t)NARR * 3 * PLANE * sizeof(T); }
+};
+
+template <typename T, int TY, int TZ>
+struct LdsSampler {
+  typedef VTile<T, TY, TZ> V;
+  const T* base;          // smem + this thread's centre (ty + 1, tz + 1)
+  int slot[3];            // element offsets of the ring slots holding planes x-1, x, x+1
+  // array ids: 0..2 velocity components, 2 + p volume class p (1..7)
+  __device__ __forceinline__ double at(int arr, int ox, int oy, int oz) const {
+    return (double)base[arr * 3 * V::PLANE + slot[ox + 1] + oy * V::PZ + oz];
+  }
+  __device__ __forceinline__ double vol(int p, int ox, int oy, int oz) const { return at(2 + p, ox, oy, oz); }
+  __device__ __forceinline__ double vel(int comp, int dx, int dy, int dz) const { return at(comp, dx, dy, dz); }
+  __device__ __forceinline__ bool tap_ok(int, int, int, int) const { return true; }
+};
+
+template <typename T, int TY, int TZ>
+__global__ void __launch_bounds__(TY * TZ)
+k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy,
+                  T* __restrict__ oz, int xchunk, int nbz, int nby, int xcd_order, double* __restrict__ partial,
+                  const double* __restrict__ done_flag) {
+  typedef VTile<T, TY, TZ> V;
+  if (done_flag && *done_flag != 0.0) return;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* const smem = reinterpret_cast<T*>(smem_raw);
+  const int Nx = c.N[0], Ny = c.N[1], Nz = c.N[2];
+  const int tid = threadIdx.x;
+  const int lb = xcd_logical_block(xcd_order);
+  const int bz = lb % nbz, by = (lb / nbz) % nby, bxk = lb / (nbz * nby);
+  const int y0 = 1 + by * TY, z0 = 1 + bz * TZ;               // first cell of the tile
+  const int ty = tid / TZ, tz = tid - ty * TZ;
+  const int yr = y0 + ty, zr = z0 + tz;
+  const bool active = zr <= Nz - 2 && yr <= Ny - 2;
+  const int y = min(yr, Ny - 2), z = min(zr, Nz - 2);          // mask / store addresses of inactive lanes stay valid
+  const int x0 = 1 + bxk * xchunk, x1 = min(x0 + xchunk, Nx - 1);
+  // the ten arrays: base pointer, rows per plane, row length
+  const T* ap[V::NARR];
+  int d1[V::NARR], d2[V::NARR];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { ap[a] = v.p[a]; d1[a] = Ny + (a == 1); d2[a] = Nz + (a == 2); }
+#pragma unroll
+  for (int p = 1; p < 8; ++p) { ap[2 + p] = (const T*)c.vol[p]; d1[2 + p] = c.dim(p, 1); d2[2 + p] = c.dim(p, 2); }
+  // staging slots of this thread: tile element e = tid + k * BLOCK  <->  (y0 - 1 + e / PZ, z0 - 1 + e % PZ)
+  int se[V::NSTG], sgy[V::NSTG], sgz[V::NSTG];
+#pragma unroll
+  for (int k = 0; k < V::NSTG; ++k) {
+    se[k] = tid + k * V::BLOCK;
+    const int ly = se[k] / V::PZ;
+    sgy[k] = y0 - 1 + ly;
+    sgz[k] = z0 - 1 + (se[k] - ly * V::PZ);
+  }
+  T stg[V::NARR][V::NSTG];
+  auto stage_load = [&](int X) {
+#pragma unroll
+    for (int a = 0; a < V::NARR; ++a) {
+#pragma unroll
+      for (int k = 0; k < V::NSTG; ++k) {
+        const bool ok = se[k] < V::PLANE && sgy[k] < d1[a] && sgz[k] < d2[a];
+        // clamped address, unconditional load: the prefetch stays free of control flow
+        const int gy = min(sgy[k], d1[a] - 1), gz = min(sgz[k], d2[a] - 1);
+        const T val = ap[a][((int64_t)X * d1[a] + gy) * d2[a] + gz];
+        stg[a][k] = ok ? val : (T)0;
+      }
+    }
+  };
+  auto stage_store = [&](int slot_off) {
+#pragma unroll
+    for (int a = 0; a < V::NARR; ++a) {
+#pragma unroll
+      for (int k = 0; k < V::NSTG; ++k)
+        if (se[k] < V::PLANE) smem[a * 3 * V::PLANE + slot_off + se[k]] = stg[a][k];
+    }
+  };
+  LdsSampler<T, TY, TZ> smp;
+  smp.base = smem + (ty + 1) * V::PZ + tz + 1;
+  smp.slot[0] = 0; smp.slot[1] = V::PLANE; smp.slot[2] = 2 * V::PLANE;
+  // prologue: planes x0-1, x0, x0+1
+  stage_load(x0 - 1); stage_store(smp.slot[0]);
+  stage_load(x0);     stage_store(smp.slot[1]);
+  stage_load(x0 + 1); stage_store(smp.slot[2]);
+  MFS_VISC_LDS_BARRIER();
+  double acc = 0.0;
+  for (int x = x0; x < x1; ++x) {
+    const bool more = x + 1 < x1;
+    if (more) stage_load(x + 2);                               // in flight while this plane is computed
+    const int64_t f0 = ((int64_t)x * Ny + y) * Nz + z, f1 = ((int64_t)x * (Ny + 1) + y) * Nz + z,
+                  f2 = ((int64_t)x * Ny + y) * (Nz + 1) + z;
+    const bool ok0 = c.msk[face_class(0)][f0] != 0, ok1 = c.msk[face_class(1)][f1] != 0,
+               ok2 = c.msk[face_class(2)][f2] != 0;
+    double o0, o1, o2;
+    const double r0 = vcg_row_s<0, false>(smp, k1, k2, ok0, o0);
+    const double r1 = vcg_row_s<1, false>(smp, k1, k2, ok1, o1);
+    const double r2 = vcg_row_s<2, false>(smp, k1, k2, ok2, o2);
+    if (active) {
+      const T t0 = (T)r0, t1 = (T)r1, t2 = (T)r2;
+      ox[f0] = t0;
+      oy[f1] = t1;
+      oz[f2] = t2;
+      acc += o0 * (double)t0 + o1 * (double)t1 + o2 * (double)t2;
+    }
+    if (more) {
+      MFS_VISC_LDS_BARRIER();                                  // everyone is done with plane x-1's slot
+      stage_store(smp.slot[0]);                                // ... which now receives plane x+2
+      MFS_VISC_LDS_BARRIER();
+      const int s0 = smp.slot[0];
+      smp.slot[0] = smp.slot[1]; smp.slot[1] = smp.slot[2]; smp.slot[2] = s0;
+    }
+  }
+  const double tot = block_sum<V::BLOCK>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
 }  // namespace mfs
 
 using namespace mfs;
@@ -381,6 +581,9 @@ struct mfs_vcg3d {
   bool is_setup;
   int grid_row;
   int mask_cg;   // 1: keep the tap masks in CG applies too (debug / A-B)
+  int tiled;     // 1: CG applies use the LDS-staged kernel (default); 0: the direct-load fused kernel
+  int xchunk_tiled;
+  int xcd_order;   // 1 / 0: XCD-contiguous tile order on / off; -1 auto
 };
 
 static int64_t class_count(const int64_t gres[3], int p) {
@@ -434,9 +637,28 @@ static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial,
     int xchunk = 8;
     while ((int64_t)nbz * nby * ((Nx - 2 + xchunk - 1) / xchunk) > 4096) xchunk *= 2;
     const int grid = nbz * nby * ((Nx - 2 + xchunk - 1) / xchunk);
-    hipLaunchKernelGGL((k_vcg_apply_fused<T, MASK>), dim3(grid), dim3(256), 0, st, h->cp, h->k1, h->k2, vv,
-                       ob + h->off[0], ob + h->off[1], ob + h->off[2], xchunk, nbz, nby, partial + used, done);
-    used += grid;
+    // XCD-contiguous tile order pays while the operands are Infinity-Cache resident (128^3: -9 %); beyond that the
+    // plain order is faster (256^3: +7 % with it) -- auto unless MFS_VISC_XCD is set
+    const double ws = 13.0 * (double)Nx * Ny * Nz * sizeof(T);
+    const int xcd = h->xcd_order < 0 ? (ws < 200e6 ? 1 : 0) : h->xcd_order;
+    if (!MASK && h->tiled) {
+      // LDS-staged tiles: 4 x 64 cells (fp32) / 4 x 32 (fp64) so that three planes of ten arrays fit 48 KB
+      constexpr int TZ = sizeof(T) == 4 ? 64 : 32;
+      const int tbz = (Nz - 2 + TZ - 1) / TZ;
+      int xc = h->xchunk_tiled;
+      while ((int64_t)tbz * nby * ((Nx - 2 + xc - 1) / xc) > 4096) xc *= 2;
+      const int tgrid = tbz * nby * ((Nx - 2 + xc - 1) / xc);
+      typedef VTile<T, 4, TZ> Tile;
+      const size_t lds = Tile::lds_bytes();
+      hipLaunchKernelGGL((k_vcg_apply_tiled<T, 4, TZ>), dim3(tgrid), dim3(4 * TZ), lds, st, h->cp,
+                         h->k1, h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], xc, tbz, nby, xcd, partial + used,
+                         done);
+      used += tgrid;
+    } else {
+      hipLaunchKernelGGL((k_vcg_apply_fused<T, MASK>), dim3(grid), dim3(256), 0, st, h->cp, h->k1, h->k2, vv,
+                         ob + h->off[0], ob + h->off[1], ob + h->off[2], xchunk, nbz, nby, xcd, partial + used, done);
+      used += grid;
+    }
   }
   // (2) the three slabs of interior faces outside that box: u at x = Nx-1, v at y = Ny-1, w at z = Nz-1
   auto slab = [&](int ax) {
@@ -450,20 +672,28 @@ static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial,
     const int64_t n = (int64_t)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
     return (int)std::max<int64_t>(1, std::min<int64_t>(256, (n + 255) / 256));
   };
-  if (Nx >= 2 && Ny >= 3 && Nz >= 3) {
-    const Box3 b = slab(0); const int g = sgrid(b);
-    hipLaunchKernelGGL((k_vcg_apply_row<T, 0, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[0], b, partial + used, done);
-    used += g;
-  }
-  if (Nx >= 3 && Ny >= 2 && Nz >= 3) {
-    const Box3 b = slab(1); const int g = sgrid(b);
-    hipLaunchKernelGGL((k_vcg_apply_row<T, 1, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[1], b, partial + used, done);
-    used += g;
-  }
-  if (Nx >= 3 && Ny >= 3 && Nz >= 2) {
-    const Box3 b = slab(2); const int g = sgrid(b);
-    hipLaunchKernelGGL((k_vcg_apply_row<T, 2, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[2], b, partial + used, done);
-    used += g;
+  if (Nx >= 3 && Ny >= 3 && Nz >= 3) {
+    const Box3 b0 = slab(0), b1 = slab(1), b2 = slab(2);
+    const int g0 = sgrid(b0), g1 = sgrid(b1), g2 = sgrid(b2);
+    hipLaunchKernelGGL((k_vcg_apply_slabs<T, MASK>), dim3(g0 + g1 + g2), dim3(256), 0, st, h->cp, h->k1, h->k2, vv,
+                       ob + h->off[0], ob + h->off[1], ob + h->off[2], b0, b1, b2, g0, g1, partial + used, done);
+    used += g0 + g1 + g2;
+  } else {   // degenerate grids: whichever slabs exist, one launch each
+    if (Nx >= 2 && Ny >= 3 && Nz >= 3) {
+      const Box3 b = slab(0); const int g = sgrid(b);
+      hipLaunchKernelGGL((k_vcg_apply_row<T, 0, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[0], b, partial + used, done);
+      used += g;
+    }
+    if (Nx >= 3 && Ny >= 2 && Nz >= 3) {
+      const Box3 b = slab(1); const int g = sgrid(b);
+      hipLaunchKernelGGL((k_vcg_apply_row<T, 1, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[1], b, partial + used, done);
+      used += g;
+    }
+    if (Nx >= 3 && Ny >= 3 && Nz >= 2) {
+      const Box3 b = slab(2); const int g = sgrid(b);
+      hipLaunchKernelGGL((k_vcg_apply_row<T, 2, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[2], b, partial + used, done);
+      used += g;
+    }
   }
   MFS_LAUNCH_CHECK();
   *nparts = used;
@@ -642,6 +872,9 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
   h->is_setup = false;
   h->mask_cg = env_int("MFS_VISC_MASK_CG", 0);
+  h->tiled = env_int("MFS_VISC_TILED", 0);   // measured slower than the direct-load kernel; kept selectable
+  h->xcd_order = env_int("MFS_VISC_XCD", -1);
+  h->xchunk_tiled = std::max(1, env_int("MFS_VISC_XCHUNK", 32));
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
     set_error("hipMemsetAsync(workspace) failed");
