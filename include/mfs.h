@@ -349,6 +349,36 @@ int mfs_grid_boundary_condition3d(const int64_t gres[3], const void* gvx, const 
                                   const void* sphi, int sphi_dt, const void* sv, int sv_dt, double dx,
                                   void* dvx, void* dvy, void* dvz, int dv_dt, mfs_stream stream);
 
+/* ------------------------------------------------------------------------- */
+/* Notebook particle <-> grid transfers                  */
+/* ------------------------------------------------------------------------- */
+/* Particle arrays: px, pv, pca are (P,3) row-major, pm is (P).  The reference kernels keep float32
+ * locals whatever the array dtypes; `bound_min` and `grid_bias` are therefore used at float32 precision
+ * and `cell_size` at float64 -- the notebook's container dtypes (code cell 9) -- so that base indices and
+ * weights equal the reference's.  Scatters use fp atomics (order unspecified, as in the reference).     */
+/* replaces p2g_particle -- 3D_viscous_fluid_sim.ipynb code cell 2: APIC scatter of mass and momentum of velocity
+ * component `axis` to its face array (shape gres + e_axis; indices are clamped to gres - 1 as in the reference) */
+int mfs_p2g_scatter3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3],
+                      const double grid_bias[3], int axis, const void* px, int px_dt, const void* pm, int pm_dt,
+                      const void* pv, int pv_dt, const void* pca, int pca_dt, int64_t num_particles,
+                      void* gm, void* gv, int g_dt, mfs_stream stream);
+/* replaces p2g_grid -- code cell 2: gv /= gm wherever gm > 0 (count = elements of the face array) */
+int mfs_p2g_normalize3d(int64_t count, const void* gm, void* gv, int g_dt, mfs_stream stream);
+/* replaces g2p_particle -- code cell 3: pv[:, axis] and the affine row pca[:, :] from the face array gv */
+int mfs_g2p_gather3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3],
+                     const double grid_bias[3], int axis, const void* px, int px_dt, void* pv, int pv_dt,
+                     void* pca, int pca_dt, int64_t num_particles, const void* gv, int g_dt, mfs_stream stream);
+/* replaces compute_fls_kernel -- code cell 4: phi = min(phi, |cell centre - x| - radius) over the 5^3 cells around
+ * each particle (atomic min).  The caller pre-fills phi (the notebook: `ls.phi[:] = gdx * 3`).               */
+int mfs_fluid_levelset3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3], double radius,
+                         const void* px, int px_dt, int64_t num_particles, void* phi, int phi_dt, mfs_stream stream);
+/* replaces compute_fluid_volume_kernel + constrain_fluid_volume_kernel -- code cell 6: trilinear splat of the
+ * particle volume onto the nodes of the array `gvol` (shape vres, spacing cell_size), then min(., cell volume).
+ * The caller zeroes gvol first (the notebook: `fv.vol[:] = 0.0`).                                            */
+int mfs_fluid_volume3d(const int64_t vres[3], const double bound_min[3], const double cell_size[3],
+                       const void* px, int px_dt, double pvol, int64_t num_particles, void* gvol, int g_dt,
+                       mfs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

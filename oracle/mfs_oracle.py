@@ -816,3 +816,124 @@ class DensityCGSolver3D:
         density_advect3d(px, self.dx, self.bound_min, self.cell_size, (0, 0.5, 0.5), 0)
         density_advect3d(px, self.dy, self.bound_min, self.cell_size, (0.5, 0, 0.5), 1)
         density_advect3d(px, self.dz, self.bound_min, self.cell_size, (0.5, 0.5, 0), 2)
+
+
+# =============================================================================
+# notebook particle <-> grid transfers -- 3D_viscous_fluid_sim.ipynb code cells 2,3,4,6
+# The kernels keep float32 locals (x, gx, disp, w); the roundings below follow numba's typing with the
+# notebook's container dtypes: bound_min / grid biases float32, cell sizes float64, particle arrays float64,
+# grid mass / velocity float32, level set / volume float64.
+# =============================================================================
+F32 = np.float32
+
+
+def _nb_particle_cell(px, bound_min, cell_size, bias, centre_offset=None):
+    """float32 position, base index, float32 grid position (code cell 2: `gi`, `gx`)."""
+    x32 = np.asarray(px).astype(F32)
+    bmin32, cs = np.asarray(bound_min, F32), np.asarray(cell_size, F64)
+    t = (x32 - bmin32).astype(F64) / cs                       # float32 difference, float64 quotient
+    if bias is not None:
+        t = t - np.asarray(bias, F32).astype(F64)
+    gi = np.floor(t).astype(np.int64)
+    off = np.asarray(bias, F32).astype(F64) if centre_offset is None else centre_offset
+    gx32 = ((gi + off) * cs + bmin32.astype(F64)).astype(F32)
+    return x32, gi, gx32
+
+
+def nb_p2g_scatter(px, pm, pv, pca, gm, gv, bound_min, gres, grid_bias, cell_size, axis):
+    """p2g_particle (code cell 2): APIC scatter of mass and momentum of component `axis` to its faces."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    cs = np.asarray(cell_size, F64)
+    x32, gi, gx32 = _nb_particle_cell(px, bound_min, cs, grid_bias)
+    disp = gx32 - x32                                          # float32
+    w = (np.abs(disp).astype(F64) / cs).astype(F32).astype(F64)
+    v32 = np.asarray(pv).astype(F32)
+    m, pca = np.asarray(pm, F64), np.asarray(pca, F64)
+    d64 = disp.astype(F64)
+    for ix in (0, 1):
+        for iy in (0, 1):
+            for iz in (0, 1):
+                cx = np.clip(gi[:, 0] + ix, 0, Nx - 1)
+                cy = np.clip(gi[:, 1] + iy, 0, Ny - 1)
+                cz = np.clip(gi[:, 2] + iz, 0, Nz - 1)
+                wx = ix + ((-1) ** ix) * (1 - w[:, 0])
+                wy = iy + ((-1) ** iy) * (1 - w[:, 1])
+                wz = iz + ((-1) ** iz) * (1 - w[:, 2])
+                cv = ((d64[:, 0] + ix * cs[0]) * pca[:, 0] + (d64[:, 1] + iy * cs[1]) * pca[:, 1]
+                      + (d64[:, 2] + iz * cs[2]) * pca[:, 2])
+                weight = wx * wy * wz
+                np.add.at(gm, (cx, cy, cz), (weight * m).astype(gm.dtype))
+                np.add.at(gv, (cx, cy, cz), (weight * m * (v32[:, axis].astype(F64) + cv)).astype(gv.dtype))
+
+
+def nb_p2g_normalize(gm, gv):
+    """p2g_grid (code cell 2): momentum -> velocity where mass landed."""
+    m = gm > 0
+    gv[m] = gv[m] / gm[m]
+
+
+def nb_g2p_gather(bound_min, gres, grid_bias, cell_size, axis, px, pv, pca, gv):
+    """g2p_particle (code cell 3): trilinear velocity and its affine row, in the kernel's accumulation order."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    cs = np.asarray(cell_size, F64)
+    x32, gi, gx32 = _nb_particle_cell(px, bound_min, cs, grid_bias)
+    w = (np.abs(gx32 - x32).astype(F64) / cs).astype(F32).astype(F64)
+    pca[:, :] = 0
+    vel = np.zeros(len(x32))
+    G = np.asarray(gv)
+    for ix in (0, 1):
+        for iy in (0, 1):
+            for iz in (0, 1):
+                cx = np.clip(gi[:, 0] + ix, 0, Nx - 1)
+                cy = np.clip(gi[:, 1] + iy, 0, Ny - 1)
+                cz = np.clip(gi[:, 2] + iz, 0, Nz - 1)
+                wx = 1 - ix + (2 * ix - 1) * w[:, 0]
+                wy = 1 - iy + (2 * iy - 1) * w[:, 1]
+                wz = 1 - iz + (2 * iz - 1) * w[:, 2]
+                g = G[cx, cy, cz].astype(F64)
+                vel = vel + wx * wy * wz * g
+                pca[:, 0] += (2 * ix - 1) * wy * wz * g / cs[0]
+                pca[:, 1] += wx * (2 * iy - 1) * wz * g / cs[1]
+                pca[:, 2] += wx * wy * (2 * iz - 1) * g / cs[2]
+    pv[:, axis] = vel
+
+
+def nb_fluid_levelset(px, phi, bound_min, cell_size, gdx, gres):
+    """compute_fluid_levelset (code cell 4): phi = min over particles within +-2 cells of |centre - x| - r."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    cs = np.asarray(cell_size, F64)
+    r = gdx * 0.5 * np.sqrt(3.0) * 1.02
+    phi[...] = gdx * 3
+    x32, gi, _ = _nb_particle_cell(px, bound_min, cs, None, centre_offset=0.5)
+    bmin = np.asarray(bound_min, F32).astype(F64)
+    x64 = x32.astype(F64)
+    for dx in range(-2, 3):
+        for dy in range(-2, 3):
+            for dz in range(-2, 3):
+                ii = np.stack([np.clip(gi[:, 0] + dx, 0, Nx - 1), np.clip(gi[:, 1] + dy, 0, Ny - 1),
+                               np.clip(gi[:, 2] + dz, 0, Nz - 1)], axis=1)
+                gip = ((ii + 0.5) * cs + bmin - x64).astype(F32)
+                n = np.zeros(len(x32))
+                for d in range(3):
+                    n = n + (gip[:, d] * gip[:, d]).astype(F64)           # float32 product, float64 sum
+                np.minimum.at(phi, (ii[:, 0], ii[:, 1], ii[:, 2]), n ** 0.5 - r)
+
+
+def nb_fluid_volume(bound_min, cell_size, gres, px, pvol, gvol):
+    """compute_fluid_volume (code cell 6): trilinear splat of the particle volume onto the doubled-grid nodes,
+    clamped to the node's cell volume."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    cs = np.asarray(cell_size, F64)
+    gvol[...] = 0.0
+    x32, gi, gx32 = _nb_particle_cell(px, bound_min, cs, None, centre_offset=0.0)
+    w = (np.abs(gx32 - x32).astype(F64) / cs).astype(F32).astype(F64)
+    for ix in (0, 1):
+        for iy in (0, 1):
+            for iz in (0, 1):
+                cx = np.clip(gi[:, 0] + ix, 0, Nx - 1)
+                cy = np.clip(gi[:, 1] + iy, 0, Ny - 1)
+                cz = np.clip(gi[:, 2] + iz, 0, Nz - 1)
+                weight = ((ix + ((-1) ** ix) * (1 - w[:, 0])) * (iy + ((-1) ** iy) * (1 - w[:, 1]))
+                          * (iz + ((-1) ** iz) * (1 - w[:, 2])))
+                np.add.at(gvol, (cx, cy, cz), weight * float(pvol))
+    np.minimum(gvol, float(np.prod(cs)), out=gvol)

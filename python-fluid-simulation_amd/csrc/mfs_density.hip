@@ -11,6 +11,10 @@
 
 #include "mfs_common.h"
 
+// No FMA contraction in this file: base indices, float32-rounded grid positions and weights must round where
+// the reference's separate multiply and add round (a contracted a*b+c flips a float32 rounding now and then).
+#pragma clang fp contract(off)
+
 namespace mfs {
 
 struct DGrid {

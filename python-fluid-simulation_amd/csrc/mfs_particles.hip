@@ -1,0 +1,296 @@
+// mfs_particles.hip -- the notebook's particle <-> grid transfers on gfx950.
+//
+// Reference: 3D_viscous_fluid_sim.ipynb code cells 2 (p2g), 3 (g2p), 4 (compute_fluid_levelset) and
+// 6 (compute_fluid_volume).  One thread per particle; scatters use hardware fp atomics (the reference
+// uses cuda.atomic.add / atomic.min, whose order is unspecified too).  The reference kernels keep
+// float32 LOCALS (x, gx, disp, w) whatever the arrays' dtypes; the helpers below reproduce numba's
+// typing of those mixed expressions for the notebook's containers -- bound_min and the grid biases
+// float32, cell sizes float64 -- so that base indices and weights are the reference's, bit for bit.
+#include <math.h>
+
+#include "mfs_common.h"
+
+// No FMA contraction in this file: base indices, float32-rounded grid positions and weights must round where
+// the reference's separate multiply and add round (a contracted a*b+c flips a float32 rounding now and then).
+#pragma clang fp contract(off)
+
+namespace mfs {
+
+struct PGrid {            // clamp extents (the `gres` argument of the kernel) and the target array's shape
+  int N[3];
+  int s1, s2;             // rows / row length of the target array
+  __device__ __forceinline__ int64_t at(int x, int y, int z) const { return ((int64_t)x * s1 + y) * s2 + z; }
+};
+struct PGeom {
+  float bmin[3];          // bound_min at float32 (the notebook's BOUND_MIN is a float32 array)
+  double cs[3];           // cell_size (float64: float32 / int64 in cupy)
+  double off[3];          // sample position offset: the float32 grid bias, or 0.5 / 0 for the level set / volume
+  int has_bias;           // 1: `... / cell_size - grid_bias` (p2g, g2p); 0: no bias term in the index (cells 4, 6)
+};
+
+// x (float32), gi = floor(...), gx (float32) exactly as the kernels compute them
+__device__ __forceinline__ void nb_cell(const void* px, int pdt, int64_t P, const PGeom& g, float x[3], long long gi[3],
+                                        float gx[3]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    x[d] = (float)ldx(px, pdt, 3 * P + d);
+    double t = (double)(x[d] - g.bmin[d]) / g.cs[d];               // float32 difference, float64 quotient
+    if (g.has_bias) t -= g.off[d];
+    gi[d] = (long long)floor(t);
+    gx[d] = (float)(((double)gi[d] + g.off[d]) * g.cs[d] + (double)g.bmin[d]);
+  }
+}
+
+__device__ __forceinline__ void atomic_add_t(void* p, int dt, int64_t i, double v) {
+  if (dt == MFS_F32) atomicAdd((float*)p + i, (float)v); else atomicAdd((double*)p + i, v);
+}
+
+__device__ __forceinline__ void atomic_min_t(void* p, int dt, int64_t i, double v) {
+  if (dt == MFS_F32) {
+    int* a = (int*)p + i;
+    const float fv = (float)v;
+    int old = *a, assumed;
+    do {
+      assumed = old;
+      if (__int_as_float(assumed) <= fv) break;
+      old = atomicCAS(a, assumed, __float_as_int(fv));
+    } while (assumed != old);
+  } else {
+    unsigned long long* a = (unsigned long long*)p + i;
+    unsigned long long old = *a, assumed;
+    do {
+      assumed = old;
+      if (__longlong_as_double((long long)assumed) <= v) break;
+      old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    } while (assumed != old);
+  }
+}
+
+__device__ __forceinline__ int clampi(long long v, int n) { return (int)max(0LL, min((long long)n - 1, v)); }
+
+// p2g_particle (code cell 2)
+__global__ void __launch_bounds__(256)
+k_p2g_scatter(PGrid g, PGeom geo, int axis, const void* px, int pxdt, const void* pm, int pmdt, const void* pv, int pvdt,
+              const void* pca, int pcdt, int64_t P, void* gm, void* gv, int gdt) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const double m = ldx(pm, pmdt, p);
+  float x[3], gx[3], disp[3], w[3];
+  long long gi[3];
+  nb_cell(px, pxdt, p, geo, x, gi, gx);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    disp[d] = gx[d] - x[d];
+    w[d] = (float)((double)fabsf(disp[d]) / geo.cs[d]);
+  }
+  const float va = (float)ldx(pv, pvdt, 3 * p + axis);
+  const double c0 = ldx(pca, pcdt, 3 * p), c1 = ldx(pca, pcdt, 3 * p + 1), c2 = ldx(pca, pcdt, 3 * p + 2);
+  for (int ix = 0; ix < 2; ++ix)
+    for (int iy = 0; iy < 2; ++iy)
+      for (int iz = 0; iz < 2; ++iz) {
+        const int cx = clampi(gi[0] + ix, g.N[0]), cy = clampi(gi[1] + iy, g.N[1]), cz = clampi(gi[2] + iz, g.N[2]);
+        const double wx = ix + (ix ? -1.0 : 1.0) * (1 - (double)w[0]);
+        const double wy = iy + (iy ? -1.0 : 1.0) * (1 - (double)w[1]);
+        const double wz = iz + (iz ? -1.0 : 1.0) * (1 - (double)w[2]);
+        const double cv = ((double)disp[0] + ix * geo.cs[0]) * c0 + ((double)disp[1] + iy * geo.cs[1]) * c1 +
+                          ((double)disp[2] + iz * geo.cs[2]) * c2;
+        const double weight = wx * wy * wz;
+        const int64_t c = g.at(cx, cy, cz);
+        atomic_add_t(gm, gdt, c, weight * m);
+        atomic_add_t(gv, gdt, c, weight * m * ((double)va + cv));
+      }
+}
+
+// p2g_grid (code cell 2): gv /= gm where mass landed, in the arrays' own precision
+__global__ void __launch_bounds__(256) k_p2g_normalize(int64_t n, const void* gm, void* gv, int gdt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (gdt == MFS_F32) {
+    const float m = ((const float*)gm)[i];
+    if (m > 0) ((float*)gv)[i] = ((float*)gv)[i] / m;
+  } else {
+    const double m = ((const double*)gm)[i];
+    if (m > 0) ((double*)gv)[i] = ((double*)gv)[i] / m;
+  }
+}
+
+// g2p_particle (code cell 3): pv[P, axis] and the affine row pca[P, :] are accumulated INTO the array
+// elements in the reference, so with float32 particle arrays every partial sum is rounded to float32.
+__global__ void __launch_bounds__(256)
+k_g2p_gather(PGrid g, PGeom geo, int axis, const void* px, int pxdt, void* pv, int pvdt, void* pca, int pcdt, int64_t P,
+             const void* gv, int gdt) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float x[3], gx[3], w[3];
+  long long gi[3];
+  nb_cell(px, pxdt, p, geo, x, gi, gx);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) w[d] = (float)((double)fabsf(gx[d] - x[d]) / geo.cs[d]);
+  double vel = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  auto acc = [](double s, double t, int dt) { return dt == MFS_F32 ? (double)(float)(s + t) : s + t; };
+  for (int ix = 0; ix < 2; ++ix)
+    for (int iy = 0; iy < 2; ++iy)
+      for (int iz = 0; iz < 2; ++iz) {
+        const int cx = clampi(gi[0] + ix, g.N[0]), cy = clampi(gi[1] + iy, g.N[1]), cz = clampi(gi[2] + iz, g.N[2]);
+        const double wx = 1 - ix + (2 * ix - 1) * (double)w[0];
+        const double wy = 1 - iy + (2 * iy - 1) * (double)w[1];
+        const double wz = 1 - iz + (2 * iz - 1) * (double)w[2];
+        const double gval = ldx(gv, gdt, g.at(cx, cy, cz));
+        vel = acc(vel, wx * wy * wz * gval, pvdt);
+        a0 = acc(a0, (2 * ix - 1) * wy * wz * gval / geo.cs[0], pcdt);
+        a1 = acc(a1, wx * (2 * iy - 1) * wz * gval / geo.cs[1], pcdt);
+        a2 = acc(a2, wx * wy * (2 * iz - 1) * gval / geo.cs[2], pcdt);
+      }
+  stx(pv, pvdt, 3 * p + axis, vel);
+  stx(pca, pcdt, 3 * p, a0);
+  stx(pca, pcdt, 3 * p + 1, a1);
+  stx(pca, pcdt, 3 * p + 2, a2);
+}
+
+// compute_fls_kernel (code cell 4): phi = min(phi, |cell centre - x| - r) over the 5^3 cells around the particle
+__global__ void __launch_bounds__(256)
+k_fluid_levelset(PGrid g, PGeom geo, double r, const void* px, int pxdt, int64_t P, void* phi, int phidt) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float x[3], gx[3];
+  long long gi[3];
+  nb_cell(px, pxdt, p, geo, x, gi, gx);
+  for (int dx = -2; dx <= 2; ++dx)
+    for (int dy = -2; dy <= 2; ++dy)
+      for (int dz = -2; dz <= 2; ++dz) {
+        const int ii[3] = {clampi(gi[0] + dx, g.N[0]), clampi(gi[1] + dy, g.N[1]), clampi(gi[2] + dz, g.N[2])};
+        double n = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const float gip = (float)(((double)ii[d] + 0.5) * geo.cs[d] + (double)geo.bmin[d] - (double)x[d]);
+          n += (double)(gip * gip);                              // float32 product, float64 sum (norm())
+        }
+        atomic_min_t(phi, phidt, g.at(ii[0], ii[1], ii[2]), sqrt(n) - r);
+      }
+}
+
+// compute_fluid_volume_kernel (code cell 6)
+__global__ void __launch_bounds__(256)
+k_fluid_volume_splat(PGrid g, PGeom geo, const void* px, int pxdt, double pvol, int64_t P, void* gvol, int gdt) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float x[3], gx[3], w[3];
+  long long gi[3];
+  nb_cell(px, pxdt, p, geo, x, gi, gx);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) w[d] = (float)((double)fabsf(gx[d] - x[d]) / geo.cs[d]);
+  for (int ix = 0; ix < 2; ++ix)
+    for (int iy = 0; iy < 2; ++iy)
+      for (int iz = 0; iz < 2; ++iz) {
+        const int cx = clampi(gi[0] + ix, g.N[0]), cy = clampi(gi[1] + iy, g.N[1]), cz = clampi(gi[2] + iz, g.N[2]);
+        const double weight = (ix + (ix ? -1.0 : 1.0) * (1 - (double)w[0])) * (iy + (iy ? -1.0 : 1.0) * (1 - (double)w[1])) *
+                              (iz + (iz ? -1.0 : 1.0) * (1 - (double)w[2]));
+        atomic_add_t(gvol, gdt, g.at(cx, cy, cz), weight * pvol);
+      }
+}
+
+// constrain_fluid_volume_kernel (code cell 6)
+__global__ void __launch_bounds__(256) k_fluid_volume_constrain(int64_t n, void* gvol, int gdt, double cell_vol) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  stx(gvol, gdt, i, fmin(ldx(gvol, gdt, i), cell_vol));
+}
+
+static int check_shape(const int64_t s[3]) {
+  MFS_REQUIRE(s != nullptr, "shape is null");
+  for (int a = 0; a < 3; ++a) MFS_REQUIRE(s[a] >= 1 && s[a] <= 8193, "array extent out of range [1,8193]");
+  return MFS_OK;
+}
+
+static PGeom make_geom(const double bmin[3], const double cs[3], const double off[3], int has_bias) {
+  PGeom g;
+  for (int d = 0; d < 3; ++d) { g.bmin[d] = (float)bmin[d]; g.cs[d] = cs[d]; g.off[d] = (double)(float)off[d]; }
+  g.has_bias = has_bias;
+  return g;
+}
+
+}  // namespace mfs
+
+using namespace mfs;
+
+extern "C" {
+
+int mfs_p2g_scatter3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3],
+                      const double grid_bias[3], int axis, const void* px, int px_dt, const void* pm, int pm_dt,
+                      const void* pv, int pv_dt, const void* pca, int pca_dt, int64_t num_particles, void* gm, void* gv,
+                      int g_dt, mfs_stream stream) {
+  if (int e = check_shape(gres)) return e;
+  MFS_REQUIRE(bound_min && cell_size && grid_bias && gm && gv, "null argument");
+  MFS_REQUIRE(axis >= 0 && axis < 3, "axis");
+  MFS_REQUIRE(num_particles >= 0 && (num_particles == 0 || (px && pm && pv && pca)), "particle arrays");
+  MFS_REQUIRE(dtype_ok(px_dt) && dtype_ok(pm_dt) && dtype_ok(pv_dt) && dtype_ok(pca_dt) && dtype_ok(g_dt), "dtype");
+  if (num_particles == 0) return MFS_OK;
+  PGrid g{{(int)gres[0], (int)gres[1], (int)gres[2]}, (int)gres[1] + (axis == 1), (int)gres[2] + (axis == 2)};
+  hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(num_particles, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     make_geom(bound_min, cell_size, grid_bias, 1), axis, px, px_dt, pm, pm_dt, pv, pv_dt, pca, pca_dt,
+                     num_particles, gm, gv, g_dt);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+int mfs_p2g_normalize3d(int64_t count, const void* gm, void* gv, int g_dt, mfs_stream stream) {
+  MFS_REQUIRE(count >= 0 && gm && gv, "arguments");
+  MFS_REQUIRE(dtype_ok(g_dt), "dtype");
+  if (count == 0) return MFS_OK;
+  hipLaunchKernelGGL(k_p2g_normalize, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, count, gm, gv, g_dt);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+int mfs_g2p_gather3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3],
+                     const double grid_bias[3], int axis, const void* px, int px_dt, void* pv, int pv_dt, void* pca,
+                     int pca_dt, int64_t num_particles, const void* gv, int g_dt, mfs_stream stream) {
+  if (int e = check_shape(gres)) return e;
+  MFS_REQUIRE(bound_min && cell_size && grid_bias && gv, "null argument");
+  MFS_REQUIRE(axis >= 0 && axis < 3, "axis");
+  MFS_REQUIRE(num_particles >= 0 && (num_particles == 0 || (px && pv && pca)), "particle arrays");
+  MFS_REQUIRE(dtype_ok(px_dt) && dtype_ok(pv_dt) && dtype_ok(pca_dt) && dtype_ok(g_dt), "dtype");
+  if (num_particles == 0) return MFS_OK;
+  PGrid g{{(int)gres[0], (int)gres[1], (int)gres[2]}, (int)gres[1] + (axis == 1), (int)gres[2] + (axis == 2)};
+  hipLaunchKernelGGL(k_g2p_gather, dim3(cdiv(num_particles, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     make_geom(bound_min, cell_size, grid_bias, 1), axis, px, px_dt, pv, pv_dt, pca, pca_dt,
+                     num_particles, gv, g_dt);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+int mfs_fluid_levelset3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3], double radius,
+                         const void* px, int px_dt, int64_t num_particles, void* phi, int phi_dt, mfs_stream stream) {
+  if (int e = check_shape(gres)) return e;
+  MFS_REQUIRE(bound_min && cell_size && phi, "null argument");
+  MFS_REQUIRE(num_particles >= 0 && (num_particles == 0 || px), "particle array");
+  MFS_REQUIRE(dtype_ok(px_dt) && dtype_ok(phi_dt), "dtype");
+  if (num_particles == 0) return MFS_OK;
+  PGrid g{{(int)gres[0], (int)gres[1], (int)gres[2]}, (int)gres[1], (int)gres[2]};
+  const double half[3] = {0.5, 0.5, 0.5};
+  hipLaunchKernelGGL(k_fluid_levelset, dim3(cdiv(num_particles, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     make_geom(bound_min, cell_size, half, 0), radius, px, px_dt, num_particles, phi, phi_dt);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+int mfs_fluid_volume3d(const int64_t vres[3], const double bound_min[3], const double cell_size[3], const void* px,
+                       int px_dt, double pvol, int64_t num_particles, void* gvol, int g_dt, mfs_stream stream) {
+  if (int e = check_shape(vres)) return e;
+  MFS_REQUIRE(bound_min && cell_size && gvol, "null argument");
+  MFS_REQUIRE(num_particles >= 0 && (num_particles == 0 || px), "particle array");
+  MFS_REQUIRE(dtype_ok(px_dt) && dtype_ok(g_dt), "dtype");
+  PGrid g{{(int)vres[0], (int)vres[1], (int)vres[2]}, (int)vres[1], (int)vres[2]};
+  const double zero[3] = {0.0, 0.0, 0.0};
+  if (num_particles > 0)
+    hipLaunchKernelGGL(k_fluid_volume_splat, dim3(cdiv(num_particles, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       make_geom(bound_min, cell_size, zero, 0), px, px_dt, pvol, num_particles, gvol, g_dt);
+  const int64_t n = vres[0] * vres[1] * vres[2];
+  const double cell_vol = cell_size[0] * cell_size[1] * cell_size[2];          // cp.prod(fv.cell_size)
+  hipLaunchKernelGGL(k_fluid_volume_constrain, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, gvol, g_dt,
+                     cell_vol);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+}  // extern "C"

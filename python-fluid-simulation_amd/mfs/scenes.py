@@ -338,3 +338,26 @@ def density_scene_3d(gres, seed=0, *, per_cell=4, bound_min=(-0.25, 0.1, 0.0), p
     return dict(gres=(Nx, Ny, Nz), bound_min=tuple(float(b) for b in bound_min), bound_size=tuple(float(v) for v in size),
                 sphi=sc["sphi"], sv=sc["sv"], lphi=sc["lphi"], lvol=lvol, px=px, pm=pm, pvol=pvol, rho0=float(rho0),
                 dt=float(dt))
+
+
+def particle_scene_3d(gres, seed=0, *, per_cell=3, bound_min=(-0.3, 0.0, -0.3)):
+    """Inputs of the notebook's particle <-> grid transfers: jittered particles in the
+    lower part of a box with the notebook's origin (BOUND_MIN = (-0.3, 0, -0.3), ipynb code cell 9), a few of
+    them pushed up to / beyond the walls so that the index clamps are exercised; velocities and affine rows
+    random.  Cubic cells of size gdx.  numpy only."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    gdx = 0.05
+    size = np.array([Nx, Ny, Nz], np.float64) * gdx
+    rng = np.random.default_rng(seed + 2000)
+    n = per_cell * Nx * Ny * Nz // 2
+    pos = rng.uniform([0.8 * gdx, 0.8 * gdx, 0.8 * gdx], [size[0] - 0.8 * gdx, 0.55 * size[1], size[2] - 0.8 * gdx],
+                      size=(n, 3))
+    k = max(4, n // 50)                 # stragglers next to / outside the walls
+    pos[:k] = rng.uniform(-0.4 * gdx, 0.7 * gdx, size=(k, 3)) + rng.integers(0, 2, size=(k, 3)) * (size - 0.3 * gdx)
+    px = pos + np.asarray(bound_min, np.float64)
+    pvol = gdx ** 3 / per_cell
+    pm = 1000.0 * pvol * (1.0 + 0.1 * rng.standard_normal(n))
+    pv = rng.standard_normal((n, 3))
+    aff = [2.0 * rng.standard_normal((n, 3)) for _ in range(3)]
+    return dict(gres=(Nx, Ny, Nz), bound_min=tuple(float(b) for b in bound_min), bound_size=tuple(float(v) for v in size),
+                gdx=gdx, px=px, pm=pm, pv=pv, pcx=aff[0], pcy=aff[1], pcz=aff[2], pvol=float(pvol))

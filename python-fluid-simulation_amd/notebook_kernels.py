@@ -1,8 +1,13 @@
-"""Drop-ins for the notebook-local grid functions that bracket the two solves in
-3D_viscous_fluid_sim.ipynb: `extrapolate` (code cell 7, called at
-ipynb:4652) and `apply_boundary_condition` (code cell 5, called at ipynb:4655).  Same names and
-argument lists as the notebook's definitions; PyTorch-ROCm tensors; HIP kernels behind the C ABI.
-(The gravity step between them, ipynb:4608, is `grid.y.v += -10 * dt` -- a tensor expression.)"""
+"""Drop-ins for the notebook-local functions of 3D_viscous_fluid_sim.ipynb around the solves.
+SURVEY.md section 8(f) rank 1: `extrapolate` (code cell 7, called at ipynb:4652) and
+`apply_boundary_condition` (code cell 5, ipynb:4655); rank 3: the particle <-> grid transfers `p2g`
+(code cell 2, ipynb:4604), `g2p` (cell 3, ipynb:4660), `compute_fluid_levelset` (cell 4, ipynb:4587)
+and `compute_fluid_volume` (cell 6, ipynb:4588).  Same names and argument lists as the notebook's
+definitions (its `edict` containers are any objects with the same attributes); PyTorch-ROCm tensors;
+HIP kernels behind the C ABI.  (The gravity step, ipynb:4608, is `grid.y.v += -10 * dt` -- a tensor
+expression.)"""
+import math
+
 import torch
 
 from mfs import _lib, tensors as T
@@ -46,3 +51,78 @@ def apply_boundary_condition(g, solid, dx):
     g.x.v += g.x.dv
     g.y.v += g.y.dv
     g.z.v += g.z.dv
+
+
+# ------------------------------------------------------------------ particle <-> grid (rank 3)
+def _particles(t, name, cols=3):
+    t = T.dev(t, name)
+    if t.dim() != 2 or t.shape[1] != cols:
+        raise ValueError(f"{name}: expected shape (P, {cols}), got {tuple(t.shape)}")
+    return t
+
+
+def _f3(a):
+    return _lib.f64x(T.as_f64_list(a, 3))
+
+
+def p2g(p, g):
+    """Particle -> grid (code cell 2): APIC scatter of mass and momentum to the three face arrays, then
+    momentum / mass.  `p`: num_particles, x, m, v, cx, cy, cz.  `g`: resolution, bound_min, cell_size and
+    per axis g.x / g.y / g.z with m, v, bias.  The caller zeroes g.*.m and g.*.v first (ipynb:4597-4602)."""
+    gres = T.as_gres(g.resolution)
+    px, pv = _particles(p.x, "p.x"), _particles(p.v, "p.v")
+    pm = T.dev(p.m, "p.m", (px.shape[0],))
+    lib = _lib.load()
+    comps = ((g.x, p.cx, 0), (g.y, p.cy, 1), (g.z, p.cz, 2))
+    for gc, pc, axis in comps:
+        pc = _particles(pc, "p.c" + "xyz"[axis])
+        gm = T.dev(gc.m, "g.%s.m" % "xyz"[axis], T.face_shape(gres, axis))
+        gv = T.dev(gc.v, "g.%s.v" % "xyz"[axis], T.face_shape(gres, axis))
+        if gm.dtype != gv.dtype:
+            raise TypeError("grid mass and velocity must share a dtype")
+        _lib.check(lib.mfs_p2g_scatter3d(_lib.i64x(gres), _f3(g.bound_min), _f3(g.cell_size), _f3(gc.bias), axis,
+                                         T.ptr(px), T.code(px), T.ptr(pm), T.code(pm), T.ptr(pv), T.code(pv), T.ptr(pc),
+                                         T.code(pc), int(px.shape[0]), T.ptr(gm), T.ptr(gv), T.code(gm), T.stream()),
+                   "mfs_p2g_scatter3d")
+    for gc, _, axis in comps:
+        _lib.check(lib.mfs_p2g_normalize3d(int(gc.m.numel()), T.ptr(gc.m), T.ptr(gc.v), T.code(gc.m), T.stream()),
+                   "mfs_p2g_normalize3d")
+
+
+def g2p(p, g):
+    """Grid -> particle (code cell 3): p.v[:, axis] and the affine rows p.cx / p.cy / p.cz from g.*.v."""
+    gres = T.as_gres(g.resolution)
+    px, pv = _particles(p.x, "p.x"), _particles(p.v, "p.v")
+    lib = _lib.load()
+    for gc, pc, axis in ((g.x, p.cx, 0), (g.y, p.cy, 1), (g.z, p.cz, 2)):
+        pc = _particles(pc, "p.c" + "xyz"[axis])
+        gv = T.dev(gc.v, "g.%s.v" % "xyz"[axis], T.face_shape(gres, axis))
+        _lib.check(lib.mfs_g2p_gather3d(_lib.i64x(gres), _f3(g.bound_min), _f3(g.cell_size), _f3(gc.bias), axis,
+                                        T.ptr(px), T.code(px), T.ptr(pv), T.code(pv), T.ptr(pc), T.code(pc),
+                                        int(px.shape[0]), T.ptr(gv), T.code(gv), T.stream()), "mfs_g2p_gather3d")
+
+
+def compute_fluid_levelset(p, ls, gdx):
+    """Particle level set on the cell grid (code cell 4): ls.phi = gdx * 3, then the atomic-min pass with
+    radius gdx * 0.5 * sqrt(3) * 1.02."""
+    gres = T.as_gres(ls.resolution)
+    px = _particles(p.x, "p.x")
+    phi = T.dev(ls.phi, "ls.phi", gres)
+    r = gdx * 0.5 * math.sqrt(3.0) * 1.02
+    phi.fill_(gdx * 3)
+    lib = _lib.load()
+    _lib.check(lib.mfs_fluid_levelset3d(_lib.i64x(gres), _f3(ls.bound_min), _f3(ls.cell_size), float(r), T.ptr(px),
+                                        T.code(px), int(px.shape[0]), T.ptr(phi), T.code(phi), T.stream()),
+               "mfs_fluid_levelset3d")
+
+
+def compute_fluid_volume(p, fv, pvol):
+    """Fluid volume on the doubled grid (code cell 6): zero, trilinear splat of `pvol`, clamp to the cell volume."""
+    vres = T.as_gres(fv.resolution)
+    px = _particles(p.x, "p.x")
+    vol = T.dev(fv.vol, "fv.vol", vres)
+    vol.zero_()
+    lib = _lib.load()
+    _lib.check(lib.mfs_fluid_volume3d(_lib.i64x(vres), _f3(fv.bound_min), _f3(fv.cell_size), T.ptr(px), T.code(px),
+                                      float(pvol), int(px.shape[0]), T.ptr(vol), T.code(vol), T.stream()),
+               "mfs_fluid_volume3d")

@@ -66,7 +66,10 @@ def grid(ndim):
 class _Local:
     @staticmethod
     def array(n, dtype=_np.float64):
-        return _np.zeros(n, dtype=dtype)
+        # the shim's array type, so that float32 elements read back with numba's typing of mixed
+        # expressions (refshim/cupy.py:_f32) -- the notebook's particle kernels keep float32 locals
+        import cupy as _cp
+        return _cp.zeros(n, dtype=dtype)
 
 
 local = _Local()

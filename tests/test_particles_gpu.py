@@ -1,0 +1,92 @@
+"""The notebook's particle <-> grid transfers on the MI355X against goldens produced by
+executing the notebook's own cells (tests/golden/make_goldens_particles.py, pt_*), with the notebook's container
+dtypes.  Tolerances: gathers are order-exact (1e-12); scatters add with fp atomics in arbitrary order -- fp32
+grid arrays to a few fp32 ulps of the array maximum, fp64 arrays to 1e-11; the level set (an atomic min) is exact
+up to sqrt vs pow (1e-13)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_names
+import notebook_kernels as K
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+N = lambda t: t.detach().cpu().numpy()  # noqa: E731
+NS = types.SimpleNamespace
+
+
+def containers(g):
+    gres = tuple(int(v) for v in g["gres"])
+    bmin = np.asarray(g["bound_min"], np.float32)
+    bsz = np.asarray(g["bound_size"], np.float32)
+    eye = np.eye(3, dtype=int)
+
+    def comp(a, bias):
+        shape = tuple(np.array(gres) + eye[a])
+        return NS(bias=np.asarray(bias, np.float32), m=torch.zeros(shape, dtype=torch.float32, device=DEV),
+                  v=torch.zeros(shape, dtype=torch.float32, device=DEV))
+    grid = NS(resolution=gres, bound_min=bmin, bound_size=bsz, cell_size=bsz / np.asarray(gres, np.int64),
+              x=comp(0, [0, .5, .5]), y=comp(1, [.5, 0, .5]), z=comp(2, [.5, .5, 0]))
+    p = NS(num_particles=len(g["px"]), x=T(g["px"]), m=T(g["pm"]), v=T(g["pv"]), cx=T(g["pcx"]), cy=T(g["pcy"]),
+           cz=T(g["pcz"]), vol=float(g["pvol"]))
+    return gres, bmin, bsz, grid, p
+
+
+@pytest.mark.parametrize("name", golden_names("pt_"))
+def test_p2g_then_g2p(name):
+    g = golden(name)
+    gres, bmin, bsz, grid, p = containers(g)
+    K.p2g(p, grid)
+    for c in "xyz":
+        gm, gv = N(getattr(grid, c).m), N(getattr(grid, c).v)
+        np.testing.assert_allclose(gm, g[f"g{c}_m"], rtol=0, atol=4e-6 * np.abs(g[f"g{c}_m"]).max())
+        np.testing.assert_allclose(gv, g[f"g{c}_v"], rtol=5e-4, atol=5e-5 * np.abs(g[f"g{c}_v"]).max())
+        assert ((gm > 0) == (g[f"g{c}_m"] > 0)).all()
+    # gather from the GOLDEN grid (so that the comparison is order-exact)
+    for c in "xyz":
+        getattr(grid, c).v.copy_(T(g[f"g{c}_v"]))
+    K.g2p(p, grid)
+    np.testing.assert_allclose(N(p.v), g["g2p_v"], rtol=1e-12, atol=1e-13)
+    for c in "xyz":
+        np.testing.assert_allclose(N(getattr(p, "c" + c)), g["g2p_c" + c], rtol=1e-12,
+                                   atol=1e-12 * np.abs(g["g2p_c" + c]).max())
+
+
+@pytest.mark.parametrize("name", golden_names("pt_"))
+def test_fluid_levelset_and_volume(name):
+    g = golden(name)
+    gres, bmin, bsz, grid, p = containers(g)
+    ls = NS(resolution=gres, bound_min=bmin, bound_size=bsz, cell_size=bsz / np.asarray(gres, np.int64),
+            phi=torch.zeros(gres, dtype=torch.float64, device=DEV))
+    K.compute_fluid_levelset(p, ls, float(g["gdx"]))
+    np.testing.assert_allclose(N(ls.phi), g["lphi"], rtol=1e-13, atol=1e-15)
+    vres = tuple(2 * np.array(gres) + 1)
+    fv = NS(resolution=vres, bound_min=bmin, bound_size=bsz, cell_size=bsz / (2 * np.asarray(gres, np.int64)),
+            vol=torch.full(vres, 3.0, dtype=torch.float64, device=DEV))
+    K.compute_fluid_volume(p, fv, p.vol)
+    np.testing.assert_allclose(N(fv.vol), g["lvol"], rtol=0, atol=1e-11 * np.abs(g["lvol"]).max())
+    # the level set and volume are what the solvers take: lphi < 0 cells exist and every volume is within its cell
+    assert (N(ls.phi) < 0).any() and N(fv.vol).max() <= float(np.prod(fv.cell_size)) * (1 + 1e-15)
+
+
+def test_transfers_feed_the_solvers():
+    """p2g -> ... -> DensityCGSolver3D / PressureCGSolver3D accept what the transfers produce (smoke of the hand-over)."""
+    from solver.CGSolverBuffer import CGSolverBuffer
+    from solver.DensityCGSolver3D import DensityCGSolver3D
+    g, d = golden("pt_a_12"), golden("d3d_a_12")
+    gres, bmin, bsz, grid, p = containers(g)
+    ls = NS(resolution=gres, bound_min=bmin, bound_size=bsz, cell_size=bsz / np.asarray(gres, np.int64),
+            phi=torch.zeros(gres, dtype=torch.float64, device=DEV))
+    K.compute_fluid_levelset(p, ls, float(g["gdx"]))
+    buf = CGSolverBuffer(gres, precision="fp64", device=DEV)
+    ds = DensityCGSolver3D(buf, gres, bmin, bsz)
+    sphi = T(np.full(tuple(2 * np.array(gres) + 1), 1.0))       # no solid anywhere near
+    sv = torch.zeros(tuple(2 * np.array(gres) + 1) + (3,), dtype=torch.float64, device=DEV)
+    lvol = torch.zeros(tuple(2 * np.array(gres) + 1), dtype=torch.float64, device=DEV)
+    x0 = p.x.clone()
+    ds.solve(1000.0, float(d["dt"]), p.x, p.m, p.vol, None, None, None, sphi, sv, ls.phi, lvol)
+    assert ds.iterations > 0 and torch.isfinite(p.x).all() and not torch.equal(p.x, x0)
