@@ -379,6 +379,19 @@ int mfs_fluid_volume3d(const int64_t vres[3], const double bound_min[3], const d
                        const void* px, int px_dt, double pvol, int64_t num_particles, void* gvol, int g_dt,
                        mfs_stream stream);
 
+/* ------------------------------------------------------------------------- */
+/* Rigid-body signed distances -- reference solver/sdf3D.py */
+/* ------------------------------------------------------------------------- */
+/* rb_d: num_bodies x 10 x 4 float64 (generate_rb :277-305): row 0 = [type code, parameters] (code // 2:
+ * 0 sphere, 1 box, 2 cylinder; odd = flipped), rows 1-4 translation, rows 5-8 rotation, row 9 velocity.
+ * position / vel are (P,3) row-major.                                                                   */
+/* replaces evaluate_kernel -- solver/sdf3D.py:218-239 (the caller zeroes vel first, as evaluate() :266 does) */
+int mfs_sdf_evaluate3d(const void* rb_d, int64_t num_bodies, const void* position, int pos_dt, int64_t num_positions,
+                       void* sd, int sd_dt, void* vel, int vel_dt, mfs_stream stream);
+/* replaces project_kernel -- solver/sdf3D.py:241-258 (in place on position) */
+int mfs_sdf_project3d(const void* rb_d, int64_t num_bodies, void* position, int pos_dt, int64_t num_positions,
+                      mfs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

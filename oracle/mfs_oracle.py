@@ -937,3 +937,138 @@ def nb_fluid_volume(bound_min, cell_size, gres, px, pvol, gvol):
                           * (iz + ((-1) ** iz) * (1 - w[:, 2])))
                 np.add.at(gvol, (cx, cy, cz), weight * float(pvol))
     np.minimum(gvol, float(np.prod(cs)), out=gvol)
+
+
+# =============================================================================
+# rigid-body signed distances -- solver/sdf3D.py
+# rb: one (10,4) float64 block; see generate_rb :277-305.  Scalar per-point restatements (test sizes only).
+# =============================================================================
+def _sdf_to_body(rb, pos):
+    """inv_rigid (:31-40) then matvecmul4 (:19-29), in their accumulation order."""
+    T, Rm = rb[1:5], rb[5:9]
+    out = np.zeros(3)
+    for i in range(3):
+        t3 = 0.0
+        for j in range(3):
+            t3 -= Rm[j, i] * T[j, 3]
+        tmp = 0.0
+        for j in range(3):
+            tmp += Rm[j, i] * pos[j]
+        tmp += t3
+        out[i] = tmp
+    return out
+
+
+def _sdf_to_world(rb, prb):
+    """mat_TR (:12-17) then matvecmul4."""
+    T, Rm = rb[1:5], rb[5:9]
+    out = np.zeros(3)
+    for i in range(3):
+        tmp = 0.0
+        for j in range(3):
+            tmp += Rm[i, j] * prb[j]
+        tmp += T[i, 3]
+        out[i] = tmp
+    return out
+
+
+def _sdf_eval_one(rb, pos):
+    kind, flipped = int(rb[0, 0] // 2), bool(rb[0, 0] % 2)
+    if kind == 0:                                            # sphere_eval :53-66
+        d = pos - np.array([rb[1, 3], rb[2, 3], rb[3, 3]])
+        sd = (d[0] ** 2 + d[1] ** 2 + d[2] ** 2) ** 0.5 - rb[0, 1]
+    elif kind == 1:                                          # box_eval :86-108
+        prb = _sdf_to_body(rb, pos)
+        tmp, mx = 0.0, -100
+        for i in range(3):
+            disp = abs(prb[i]) - rb[0, 1 + i] / 2
+            if disp > 0:
+                tmp += disp ** 2
+            if mx < disp:
+                mx = disp
+        sd = tmp ** 0.5
+        if mx < 0:
+            sd += mx
+    else:                                                    # cylinder_eval :148-172 (y_clip: see csrc/mfs_sdf.hip header)
+        prb = _sdf_to_body(rb, pos)
+        hh = rb[0, 2] / 2
+        y_clip = -hh if prb[1] < -hh else (hh if prb[1] > hh else prb[1])
+        sd = (prb[0] ** 2 + prb[2] ** 2) ** 0.5 - rb[0, 1]
+        cap = y_clip == hh or y_clip == -hh
+        if sd < 0:
+            sd = abs(y_clip - prb[1]) if cap else max(sd, prb[1] - hh, -(prb[1] + hh))
+        elif cap:
+            sd = (sd ** 2 + abs(y_clip - prb[1]) ** 2) ** 0.5
+    return -sd if flipped else sd
+
+
+def sdf_evaluate(rb_d, sd, vel, position):
+    """evaluate :260-270 -> evaluate_kernel :218-239."""
+    vel *= 0
+    P = position.reshape(-1, 3)
+    S, V = sd.reshape(-1), vel.reshape(-1, 3)
+    for p in range(P.shape[0]):
+        min_sd, idx = 100, 0
+        for i in range(rb_d.shape[0]):
+            d = _sdf_eval_one(rb_d[i], P[p].astype(F64))
+            if d < min_sd:
+                min_sd, idx = d, i
+        S[p] = min_sd
+        if min_sd <= 0:
+            V[p, :] = rb_d[idx, -1, :3]
+
+
+def sdf_project(rb_d, position):
+    """project :272-278 -> project_kernel :241-258 (in place; every body in turn)."""
+    for p in range(position.shape[0]):
+        pos = position[p].astype(F64)
+        for i in range(rb_d.shape[0]):
+            rb = rb_d[i]
+            kind, flipped = int(rb[0, 0] // 2), bool(rb[0, 0] % 2)
+            if kind == 0:                                    # sphere_project :68-84
+                c = np.array([rb[1, 3], rb[2, 3], rb[3, 3]])
+                d = pos - c
+                dist = (d[0] ** 2 + d[1] ** 2 + d[2] ** 2) ** 0.5
+                sd = dist - rb[0, 1]
+                if flipped:
+                    sd = -sd
+                if sd < 0:
+                    pos = d / dist * rb[0, 1] + c
+            elif kind == 1:                                  # box_project :110-146
+                prb = _sdf_to_body(rb, pos)
+                h = rb[0, 1:4] / 2
+                in_out = int(np.sum((prb > h) | (prb < -h)))
+                if flipped:                                  # `% 2 and ~(in_out)`: ~ is bitwise, always true (:126)
+                    pos = _sdf_to_world(rb, np.clip(prb, -h, h))
+                elif in_out == 0:
+                    index, dist_xyz = 0, 100
+                    for k in range(3):
+                        if h[k] - prb[k] < dist_xyz:
+                            dist_xyz, index = h[k] - prb[k], k * 2
+                        if prb[k] + h[k] < dist_xyz:
+                            dist_xyz, index = prb[k] + h[k], k * 2 + 1
+                    prb[index // 2] += dist_xyz * (-1) ** (index % 2)
+                    pos = _sdf_to_world(rb, prb)
+            else:                                            # cylinder_project :174-216
+                prb = _sdf_to_body(rb, pos)
+                hh = rb[0, 2] / 2
+                y_clip = -hh if prb[1] < -hh else (hh if prb[1] > hh else prb[1])
+                dist = (prb[0] ** 2 + prb[2] ** 2) ** 0.5
+                sd = dist - rb[0, 1]
+                if flipped:
+                    if abs(y_clip) == hh or sd > 0:
+                        if sd >= 0:
+                            prb[0], prb[2] = prb[0] / dist * rb[0, 1], prb[2] / dist * rb[0, 1]
+                        prb[1] = y_clip
+                    pos = _sdf_to_world(rb, prb)
+                elif sd < 0 and abs(y_clip) != hh:
+                    mv = max(sd, prb[1] - hh, -(prb[1] + hh))
+                    if mv == sd:
+                        prb[0], prb[2] = prb[0] / dist * rb[0, 1], prb[2] / dist * rb[0, 1]
+                    elif mv == prb[1] - hh:
+                        prb[1] = hh
+                    else:
+                        prb[1] = -hh
+                    pos = _sdf_to_world(rb, prb)
+            pos = pos.astype(position.dtype).astype(F64)     # the reference writes into the array row
+        position[p] = pos

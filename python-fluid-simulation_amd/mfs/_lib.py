@@ -115,6 +115,8 @@ SIGNATURES = {
     "mfs_g2p_gather3d": (_i, [_pi64, _pd, _pd, _pd, _i, _p, _i, _p, _i, _p, _i, _i64, _p, _i, _p]),
     "mfs_fluid_levelset3d": (_i, [_pi64, _pd, _pd, _d, _p, _i, _i64, _p, _i, _p]),
     "mfs_fluid_volume3d": (_i, [_pi64, _pd, _pd, _p, _i, _d, _i64, _p, _i, _p]),
+    "mfs_sdf_evaluate3d": (_i, [_p, _i64, _p, _i, _i64, _p, _i, _p, _i, _p]),
+    "mfs_sdf_project3d": (_i, [_p, _i64, _p, _i, _i64, _p]),
     "mfs_pressure_rhs2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p]),
     "mfs_pressure_apply2d": (_i, [_pi64, _p, _p, _i, _p, _p, _i, _p, _i, _p]),
     "mfs_pressure_update2d": (_i, [_pi64, _pd, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p]),

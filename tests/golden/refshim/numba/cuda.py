@@ -25,6 +25,11 @@ class _Kernel:
     def __init__(self, fn):
         self.fn = fn
 
+    def __call__(self, *args):
+        # a @cuda.jit function called from inside another kernel's body is a plain device-function call
+        # (solver/sdf3D.py decorates its helpers with a bare @cuda.jit)
+        return self.fn(*args)
+
     def __getitem__(self, cfg):
         blocks, threads = cfg[0], cfg[1]
         if not isinstance(blocks, (tuple, list)):
