@@ -1,0 +1,142 @@
+"""The notebook's scene containers and time step (3D_viscous_fluid_sim.ipynb code cells 9 and 11) on the
+MI355X drop-ins: every stage of the loop body ipynb:4571-4667 -- advect, `sdf.project`, level set / fluid
+volume, density solve, p2g, gravity, viscosity CG, pressure CG, extrapolate, boundary condition, g2p --
+runs as HIP kernels behind the C ABI (SURVEY.md 8(f) ranks 1-4 around the two hot-path solvers).
+
+This is the driver a user of the reference's notebook switches to: same containers (attribute names of
+its `edict`s), same dtypes (bounds / biases float32, cell sizes float64, particle arrays float64, grid mass
+and velocity float32, level sets float64), same call order with the `solver='apic'` branch (the U-Net
+branch needs a checkpoint that is a remote download).  Single GPU.
+"""
+import time
+import types
+
+import numpy as np
+import torch
+
+import notebook_kernels as K
+from solver import sdf3D as sdf
+from solver.CGSolverBuffer import CGSolverBuffer
+from solver.DensityCGSolver3D import DensityCGSolver3D
+from solver.PressureCGSolver3D import PressureCGSolver3D
+from solver.ViscosityCGSolver3D import ViscosityCGSolver3D
+
+NS = types.SimpleNamespace
+
+
+def grid_positions(res, bound_min, cell_size, bias, device):
+    """get_grid_pos (code cell 9): bound_min + (float32 index + float32 bias) * cell_size, float64."""
+    ax = [torch.arange(int(r), dtype=torch.float32, device=device) for r in res]
+    idx = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1)
+    b = torch.as_tensor(np.asarray(bias, np.float32), device=device)
+    cs = torch.as_tensor(np.asarray(cell_size, np.float64), device=device)
+    bm = torch.as_tensor(np.asarray(bound_min, np.float32), device=device).to(torch.float64)
+    return (bm + (idx + b).to(torch.float64) * cs).contiguous()
+
+
+class NotebookSimulation:
+    """Containers of code cell 9 and the loop body of code cell 11.
+
+    gres, gdx: cell grid and spacing; bound_min: float32 triple; rb_d: packed rigid bodies (solver.sdf3D);
+    px: (P,3) float64 particle positions; pdx: particle spacing (mass = rho * pdx^3, volume = pdx^3)."""
+
+    def __init__(self, gres, gdx, bound_min, rb_d, px, pdx, rho=1000.0, mu=1.0, dt=1.0 / 300.0, device="cuda",
+                 precision=None):
+        dev = torch.device(device)
+        g = tuple(int(v) for v in gres)
+        self.GRES, self.GDX, self.PDX, self.RHO, self.MU, self.DT = g, float(gdx), float(pdx), float(rho), float(mu), float(dt)
+        self.device = dev
+        bmin = np.asarray(bound_min, np.float32)
+        bsz = (np.asarray(g, np.float64) * gdx).astype(np.float32)         # BOUND_SIZE is a float32 array
+        self.BOUND_MIN, self.BOUND_SIZE = bmin, bsz
+        self.rb_d = rb_d
+        px = torch.as_tensor(px, dtype=torch.float64, device=dev).contiguous()
+        n = px.shape[0]
+        z3 = lambda: torch.zeros((n, 3), dtype=torch.float64, device=dev)  # noqa: E731
+        self.particle = NS(num_particles=n, x=px, m=torch.full((n,), rho * pdx ** 3, dtype=torch.float64, device=dev),
+                           v=z3(), cx=z3(), cy=z3(), cz=z3(), vol=pdx ** 3)
+        eye = np.eye(3, dtype=np.int64)
+        cs = bsz / np.asarray(g, np.int64)                                 # float32 / int64 -> float64, as in cupy
+
+        def comp(a, bias):
+            shape = tuple(np.asarray(g) + eye[a])
+            f = lambda: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+            return NS(resolution=shape, bias=np.asarray(bias, np.float32), m=f(), v=f(), dv=f())
+        self.grid = NS(resolution=g, bound_size=bsz, bound_min=bmin, cell_size=cs, x=comp(0, [0, .5, .5]),
+                       y=comp(1, [.5, 0, .5]), z=comp(2, [.5, .5, 0]))
+        dres = tuple(2 * v + 1 for v in g)
+        dcs = bsz / (2 * np.asarray(g, np.int64))
+        self.solid_levelset = NS(resolution=dres, bound_size=bsz, bound_min=bmin, cell_size=dcs,
+                                 bias=np.zeros(3, np.float32),
+                                 phi=torch.zeros(dres, dtype=torch.float64, device=dev),
+                                 v=torch.zeros(dres + (3,), dtype=torch.float64, device=dev))
+        self.solid_levelset.pos = grid_positions(dres, bmin, dcs, self.solid_levelset.bias, dev)
+        sdf.evaluate(rb_d, self.solid_levelset.phi, self.solid_levelset.v, self.solid_levelset.pos)
+        self.fluid_levelset = NS(resolution=g, bound_size=bsz, bound_min=bmin, cell_size=cs,
+                                 phi=torch.zeros(g, dtype=torch.float64, device=dev))
+        self.fluid_volume = NS(resolution=dres, bound_size=bsz, bound_min=bmin, cell_size=dcs,
+                               vol=torch.zeros(dres, dtype=torch.float64, device=dev))
+        self.CGBuf = CGSolverBuffer(g, precision=precision, device=dev)
+        self.PressureSolver = PressureCGSolver3D(self.CGBuf, g, gdx)
+        self.DensitySolver = DensityCGSolver3D(self.CGBuf, g, bmin, bsz)
+        self.ViscositySolver = ViscosityCGSolver3D(g, bsz, precision=precision, device=dev)
+        self.current_time = 0.0
+        self.iterations = 0
+
+    def step(self, duration_left=float("inf"), timings=None):
+        """One pass of the loop body (ipynb:4571-4667, solver == 'apic').  Returns the dt it took."""
+        p, g, sl, fl, fv = self.particle, self.grid, self.solid_levelset, self.fluid_levelset, self.fluid_volume
+
+        def tick(name, t0):
+            if timings is not None:
+                torch.cuda.synchronize()
+                timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+
+        t = time.perf_counter()
+        vmax = torch.sqrt((p.v ** 2).sum(dim=-1)).max().item() if p.num_particles else 0.0
+        cfl_dt = self.GDX / max(1e-10, vmax)
+        dt = min(self.DT, cfl_dt, duration_left)
+        self.current_time += dt
+        p.x += p.v * dt
+        sdf.project(self.rb_d, p.x)
+        t = tick("advect+project", t)
+        K.compute_fluid_levelset(p, fl, self.GDX)
+        K.compute_fluid_volume(p, fv, p.vol)
+        t = tick("levelset+volume", t)
+        self.DensitySolver.solve(self.RHO, dt, p.x, p.m, p.vol, g.x.v, g.y.v, g.z.v, sl.phi, sl.v, fl.phi, fv.vol)
+        t = tick("density", t)
+        K.compute_fluid_levelset(p, fl, self.GDX)
+        K.compute_fluid_volume(p, fv, p.vol)
+        t = tick("levelset+volume", t)
+        for c in (g.x, g.y, g.z):
+            c.m.zero_()
+            c.v.zero_()
+        K.p2g(p, g)
+        g.y.v += -10 * dt                                                   # gravity
+        t = tick("p2g", t)
+        if self.MU > 0:
+            self.ViscositySolver.solve(dt, self.MU, self.RHO, g.x.v, g.y.v, g.z.v, sl.phi, sl.v, fl.phi, fv.vol)
+        t = tick("viscosity", t)
+        ds = self.DensitySolver
+        self.PressureSolver.solve(g.x.v, g.y.v, g.z.v, sl.phi, sl.v, fl.phi, wx=ds.wx, wy=ds.wy, wz=ds.wz)
+        t = tick("pressure", t)
+        K.extrapolate(self.GRES, 2, g.x.v, g.y.v, g.z.v, g.x.m, g.y.m, g.z.m)
+        K.apply_boundary_condition(g, sl, self.GDX)
+        t = tick("extrapolate+bc", t)
+        K.g2p(p, g)
+        tick("g2p", t)
+        self.iterations += 1
+        return dt
+
+
+def add_box(center, size, dx, rng, keep=None):
+    """Particle seeding of code cell 9 (`add_box`): a jittered lattice of spacing dx filling a box."""
+    center, size = np.asarray(center, np.float64), np.asarray(size, np.float64)
+    dims = (size / dx).astype(np.int64)
+    idx = np.stack(np.meshgrid(*[np.arange(n) for n in dims]), axis=-1).astype(np.float32)
+    pos = (center - 0.5 * size) + size * ((idx + 0.5) / dims)
+    pos = pos.reshape(-1, 3)
+    if keep is not None:
+        pos = pos[keep(pos)]
+    return pos + rng.standard_normal(pos.shape) * dx * 0.3

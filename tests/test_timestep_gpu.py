@@ -1,0 +1,56 @@
+"""Whole time steps of the notebook's loop (ipynb:4571-4667, solver == 'apic') on the MI355X drop-ins
+(notebook_sim.NotebookSimulation) against goldens produced by executing the notebook's cells and the reference's
+solver/ package step by step (tests/golden/make_goldens_step.py).  This is BASELINE config 5's pipeline on one GPU
+at test size.  Tolerances: the three CG solves stop at the reference's absolute tol = 1e-3 and their iterates are
+chaotic in rounding, so the state after a step agrees to solver-tolerance level, not to rounding."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+import notebook_sim as NSIM
+import solver.sdf3D as sdf
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N = lambda t: t.detach().cpu().numpy()  # noqa: E731
+
+
+def build(g):
+    gres = tuple(int(v) for v in g["gres"])
+    gdx = float(g["gdx"])
+    size = np.array(gres) * gdx
+    rb_d, rb_map = sdf.generate_rb(None, {}, 'cube', ['box', size[0] - 2 * gdx, size[1] - 2 * gdx, size[2] - 2 * gdx], flip=True,
+                                   center=[0, size[1] / 2, 0], axis=[0., 1, 0], angle=0, device=DEV)
+    rb_d, rb_map = sdf.generate_rb(rb_d, rb_map, 'ramp', ['box', 0.45, 0.05, 0.8], flip=False, center=[-0.12, 0.2, 0],
+                                   axis=[0., 0, 1], angle=-35)
+    np.testing.assert_allclose(N(rb_d), g["rb_d"], rtol=0, atol=1e-16)
+    sim = NSIM.NotebookSimulation(gres, gdx, [-0.3, 0, -0.3], rb_d, g["px0"], float(g["pdx"]), rho=float(g["rho"]),
+                                  mu=float(g["mu"]), dt=float(g["dt"]), device=DEV)
+    sim.particle.v.copy_(torch.as_tensor(g["pv0"], device=DEV))
+    return sim
+
+
+def test_scene_setup_matches_reference():
+    g = golden("step_a_12x16x12")
+    sim = build(g)
+    np.testing.assert_allclose(N(sim.solid_levelset.phi), g["sphi"], rtol=1e-13, atol=1e-15)
+
+
+def test_two_full_steps():
+    g = golden("step_a_12x16x12")
+    sim = build(g)
+    timings = {}
+    for s in range(int(g["steps"])):
+        dt = sim.step(timings=timings)
+        assert dt == pytest.approx(float(g["dts"][s]), rel=1e-12)
+        px, pv = N(sim.particle.x), N(sim.particle.v)
+        move = np.abs(g[f"px{s + 1}"] - g["px0"]).max()
+        # positions: the step moves particles by `move`; agreement to 1e-4 of that
+        np.testing.assert_allclose(px, g[f"px{s + 1}"], rtol=0, atol=1e-4 * move * (s + 1))
+        np.testing.assert_allclose(pv, g[f"pv{s + 1}"], rtol=0, atol=2e-3 * np.abs(g[f"pv{s + 1}"]).max())
+        np.testing.assert_allclose(N(sim.fluid_levelset.phi), g[f"lphi{s + 1}"], rtol=0, atol=1e-4 * float(g["gdx"]))
+        gvy = g[f"gvy{s + 1}"]
+        np.testing.assert_allclose(N(sim.grid.y.v), gvy, rtol=0, atol=5e-3 * np.abs(gvy).max())
+    assert sim.iterations == 2 and set(timings) >= {"density", "viscosity", "pressure", "p2g", "g2p"}
+    assert sim.PressureSolver.iterations > 0 and sim.ViscositySolver.iterations > 0 and sim.DensitySolver.iterations > 0
