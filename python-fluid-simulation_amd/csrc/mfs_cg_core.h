@@ -106,6 +106,12 @@ __device__ __forceinline__ double block_total_of(const double* __restrict__ part
 // of partial[0..count) in block_total_of's order (so the value is the one a following kernel would
 // compute).  Hand-off: write-through (sc1) partial store, drained, then a relaxed agent-scope ticket;
 // the block whose ticket is the last reads every partial with sc1 loads behind a workgroup barrier.
+// Arrival tickets are SHARDED: one returning atomic costs ~12 ns on its word, so 2048 arrivals on one counter would
+// serialise for ~25 us -- longer than a small grid's whole update kernel.  Blocks b with equal b % 8 (the blocks of one
+// XCD) share a shard counter on a cache line of its own; the last arriver of each shard draws a top-level ticket.
+constexpr int kTicketStride = 32;                       // unsigned words between counters (128 bytes)
+constexpr int kTicketWords = 9 * kTicketStride;         // 8 shards + the top-level counter
+
 __device__ __forceinline__ bool last_block_total(double* __restrict__ partial, int my_slot, double my_val, int count,
                                                  unsigned* ticket, unsigned nblocks, double* total) {
   __shared__ int s_last;
@@ -113,9 +119,20 @@ __device__ __forceinline__ bool last_block_total(double* __restrict__ partial, i
   if (threadIdx.x == 0) {
     __hip_atomic_store(partial + my_slot, my_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == nblocks - 1;
-    if (t == nblocks - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    const unsigned nsh = nblocks < 8u ? nblocks : 8u;
+    const unsigned shard = blockIdx.x % nsh;
+    const unsigned in_shard = (nblocks - shard + nsh - 1) / nsh;      // blocks b < nblocks with b % nsh == shard
+    unsigned* sc = ticket + shard * kTicketStride;
+    bool last = false;
+    if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+      __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                       // re-arm the shard
+      unsigned* top = ticket + 8 * kTicketStride;
+      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1) {
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // re-arm the top
+        last = true;
+      }
+    }
+    s_last = last;
   }
   __syncthreads();
   if (!s_last) return false;
@@ -344,7 +361,7 @@ struct CgCore {
   int64_t n = 0;
   size_t elt = 8;
   double *scal = nullptr, *hist = nullptr, *part_dq = nullptr, *part_rr = nullptr;
-  unsigned* tickets = nullptr;   // arrival counters of the in-launch reduction tails (zero between launches)
+  unsigned* tickets = nullptr;   // two sets of sharded arrival counters (kTicketWords each) for the in-launch reduction tails; zero between launches
   void *b = nullptr, *x = nullptr, *d = nullptr, *r = nullptr, *q = nullptr;
   int n_part_dq = 0, n_part_rr = 0;
   int grid_vec = 2048, cus = 256;
@@ -355,15 +372,17 @@ struct CgCore {
 };
 
 static inline size_t core_ws_bytes() {
-  return 256 + align_up((size_t)kHistCap * 8, 256) + 2 * align_up((size_t)kMaxPartials * 8, 256);
+  return 256 + align_up((size_t)kHistCap * 8, 256) + 2 * align_up((size_t)kMaxPartials * 8, 256) +
+         2 * align_up((size_t)kTicketWords * 4, 256);
 }
 
 // carve scalars / history / partials out of the head of the workspace; returns the first free byte
 static inline char* core_carve(CgCore& c, char* p) {
-  c.scal = (double*)p; c.tickets = (unsigned*)(p + 192); p += 256;   // 16 doubles, then the tickets
+  c.scal = (double*)p; p += 256;
   c.hist = (double*)p; p += align_up((size_t)kHistCap * 8, 256);
   c.part_dq = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
   c.part_rr = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
+  c.tickets = (unsigned*)p; p += 2 * align_up((size_t)kTicketWords * 4, 256);   // two ticket sets (zeroed with the workspace)
   return p;
 }
 
@@ -444,7 +463,12 @@ static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode 
   if (cnt < 0) cnt = c.n - off;
   MFS_REQUIRE(off >= 0 && cnt >= 0 && off + cnt <= c.n, "update range");
   const bool vec = core_vec_ok(c) && ((size_t)off * c.elt) % 16 == 0;
-  const int grid = core_vec_grid(c, vec);
+  int grid = core_vec_grid(c, vec);
+  {   // >= 8 vectors per thread on small problems: fewer, fatter blocks (and fewer arrival tickets for a tail);
+      // the same grid with or without a tail, so that the r.r partials group identically in both loop forms
+    const int64_t per = vec ? (c.dt == MFS_F32 ? 4 : 2) : 1;
+    grid = std::max(1, (int)std::min<int64_t>(grid, std::max<int64_t>(c.cus, cnt / per / (kBlock * 8))));
+  }
   const bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
   if (mode == 1) { MFS_XR_MODE(1) } else if (mode == 2) { MFS_XR_MODE(2) } else { MFS_XR_MODE(0) }
   MFS_LAUNCH_CHECK();

@@ -568,7 +568,7 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (items + kApplyBlock - 1) / kApplyBlock));
     hipLaunchKernelGGL((k_slab_edge_apply<T, VEC>), dim3(grid), dim3(kApplyBlock), 0, st, (const T*)d_cur, (T*)h->c.q,
                        (const T*)h->diag, (const T*)h->cx, (const T*)h->cy, (const T*)h->cz, L, h->Ny, h->Nz, e,
-                       h->c.part_dq, n_part, h->c.scal, p->dev, par, halo_tag, h->c.tickets + 1,
+                       h->c.part_dq, n_part, h->c.scal, p->dev, par, halo_tag, h->c.tickets + kTicketWords,
                        (int)((2 * j + 1) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 1));
     MFS_LAUNCH_CHECK();
     n_part += grid;

@@ -1,0 +1,42 @@
+"""GPU: whole time steps of the notebook's loop (BASELINE config 5's pipeline on ONE MI355X): a buckling-like
+scene scaled to an N^3 grid -- flipped container box, four slanted obstacle plates (ipynb code cell 9), a fluid
+block of (N/2)^3 cells at 8 particles per cell -- stepped with notebook_sim.NotebookSimulation; per-stage
+wall-clock (synchronised), CG iteration counts.   usage: python tools/bench_timestep.py [N] [steps] [mu]"""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "python-fluid-simulation_amd"), REPO]
+import numpy as np, torch
+import notebook_sim as NSIM
+import solver.sdf3D as sdf
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+mu = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+dev = "cuda:0"
+gdx = 1.0 / N
+size = np.array([1.0, 1.0, 1.0])
+bmin = [-0.5, 0.0, -0.5]
+rb_d, rb_map = sdf.generate_rb(None, {}, 'cube', ['box', 1 - 4 * gdx, 1 - 4 * gdx, 1 - 4 * gdx], flip=True, center=[0, 0.5, 0], device=dev)
+h = 0.35
+for nm, par, c, ax, ang in (("p1", ['box', 0.67, 0.05, 1.2], [-0.42, h, 0], [0, 0, 1], -45), ("p2", ['box', 0.67, 0.05, 1.2], [0.42, h, 0], [0, 0, 1], 45),
+                            ("p3", ['box', 1.2, 0.05, 0.67], [0, h, -0.42], [1, 0, 0], 45), ("p4", ['box', 1.2, 0.05, 0.67], [0, h, 0.42], [1, 0, 0], -45)):
+    rb_d, rb_map = sdf.generate_rb(rb_d, rb_map, nm, par, flip=False, center=c, axis=ax, angle=ang)
+rng = np.random.default_rng(0)
+t0 = time.perf_counter()
+px = NSIM.add_box([0.0, 0.7, 0.0], [0.5, 0.5, 0.5], gdx / 2, rng)
+sim = NSIM.NotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"))
+sim.particle.v[:, 0] = -2.0
+torch.cuda.synchronize()
+t_setup = time.perf_counter() - t0
+sim.step()                                  # warm-up step (allocations, first launches)
+tim, its = {}, []
+t0 = time.perf_counter()
+for _ in range(steps):
+    sim.step(timings=tim)
+    its.append((sim.DensitySolver.iterations, sim.ViscositySolver.iterations, sim.PressureSolver.iterations))
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(json.dumps({"workload": f"notebook time step {N}^3, {sim.particle.num_particles} particles, mu={mu}",
+                  "state_precision": os.environ.get("MFS_PRECISION", "fp64"), "steps": steps,
+                  "s_per_step": round(t_all / steps, 4), "setup_s": round(t_setup, 2),
+                  "stage_ms_per_step": {k: round(v / steps * 1e3, 2) for k, v in tim.items()},
+                  "cg_iterations(density,viscosity,pressure)": its}))
