@@ -190,7 +190,29 @@ def main():
             ok = agree(ok)
             tinfo["p2p_vs_rccl_history_dev"] = dev_rel
             tinfo["p2p_crosscheck"] = "ok" if ok else "FAILED -> rccl"
-            if ok:
+            if ok and args.transport == "auto":
+                # calibration (part of the warm-up, outside the timed region): the same C iterations through both
+                # transports; the timed run uses the faster one and both times are reported
+                C = 20
+
+                def probe(c):
+                    c.begin(0.0)
+                    c.iterate(5)
+                    sync()
+                    t1 = time.perf_counter()
+                    c.iterate(C)
+                    sync()
+                    tt_ = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                    if world > 1:
+                        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    return tt_.item() / C
+                t_p2p, t_rccl = probe(cg_p2p), probe(cg_rccl)
+                tinfo["calibration_ms_per_step"] = {"p2p": round(t_p2p * 1e3, 5), "rccl": round(t_rccl * 1e3, 5)}
+                if t_p2p <= t_rccl:
+                    cg, transport = cg_p2p, "p2p"
+                else:
+                    tinfo["p2p_slower_than_rccl"] = True
+            elif ok:
                 cg, transport = cg_p2p, "p2p"
 
     cg.begin(0.0)                          # tol = 0: never "converged", every step does full work
