@@ -206,9 +206,16 @@ def main():
                     if world > 1:
                         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                     return tt_.item() / C
-                t_p2p, t_rccl = probe(cg_p2p), probe(cg_rccl)
-                tinfo["calibration_ms_per_step"] = {"p2p": round(t_p2p * 1e3, 5), "rccl": round(t_rccl * 1e3, 5)}
-                if t_p2p <= t_rccl:
+                eng.slab_set_aux(False)
+                t_p2p = probe(cg_p2p)
+                eng.slab_set_aux(True)                 # edge-plane sends from a second stream
+                t_p2p_aux = probe(cg_p2p)
+                t_rccl = probe(cg_rccl)
+                tinfo["calibration_ms_per_step"] = {"p2p": round(t_p2p * 1e3, 5), "p2p_aux_stream": round(t_p2p_aux * 1e3, 5),
+                                                    "rccl": round(t_rccl * 1e3, 5)}
+                eng.slab_set_aux(t_p2p_aux < t_p2p)
+                tinfo["p2p_aux_stream"] = bool(t_p2p_aux < t_p2p)
+                if min(t_p2p, t_p2p_aux) <= t_rccl:
                     cg, transport = cg_p2p, "p2p"
                 else:
                     tinfo["p2p_slower_than_rccl"] = True

@@ -209,6 +209,9 @@ int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p);
  * The engine's grid is this rank's slab incl. one ghost / boundary plane each side.
  * A peer that does not answer within MFS_P2P_TIMEOUT_MS (default 3000) stops the solve:
  * the next poll / solve returns MFS_E_TIMEOUT.                                          */
+/* slab loop tuning: send the edge planes from a second HIP stream so that the xGMI stores overlap the interior
+ * stencil launch (costs two cross-stream event hops per iteration; default: on for planes >= 1 MiB of granules) */
+int mfs_pcg3d_slab_set_aux(mfs_pcg3d* h, int on);
 int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream);
 int mfs_pcg3d_slab_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream);
 int mfs_pcg3d_slab_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_every,

@@ -87,6 +87,11 @@ struct mfs_pcg3d {
   bool vec_ok;
   bool is_setup;
   mfs_p2p* p2p;                // peer-to-peer window of the slab loop (mfs_pcg3d_attach_p2p), or null
+  // slab loop: the edge planes of d are formed and stored into the neighbours' windows on a SECOND stream, so that
+  // the xGMI stores (whose completion the producing kernel has to wait for) overlap the interior stencil launch
+  hipStream_t aux;
+  hipEvent_t ev_main, ev_aux;
+  int use_aux;
 };
 
 // Coefficient arrays are staggered by an odd number of 4 KiB pages so that the six
@@ -232,6 +237,8 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->grid_apply = std::min(kMaxPartials, h->cus * 8);
   h->is_setup = false;
   h->p2p = nullptr;
+  h->aux = nullptr; h->ev_main = nullptr; h->ev_aux = nullptr;
+  h->use_aux = env_int("MFS_SLAB_AUX_STREAM", -1);   // -1: decided at attach time from the plane size
   if (hipMemsetAsync(workspace, 0, mfs_pcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
     set_error("hipMemsetAsync(workspace) failed");
     core_free(h->c);
@@ -244,6 +251,9 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
 
 int mfs_pcg3d_destroy(mfs_pcg3d* h) {
   if (!h) return MFS_OK;
+  if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+  if (h->ev_aux) (void)hipEventDestroy(h->ev_aux);
+  if (h->aux) (void)hipStreamDestroy(h->aux);
   core_free(h->c);
   delete h;
   return MFS_OK;
@@ -539,17 +549,25 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
   const int64_t plane_elems = (int64_t)h->Ny * h->Nz;
   const unsigned halo_tag = 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)((j + 1) & 0xfffff);
   int e_;
-  // 1. edge planes of d_j: local + into the neighbours' windows
+  // 1. edge planes of d_j: local + into the neighbours' windows -- on the second stream, behind everything
+  //    the main stream has done so far (beta, r of the previous iteration)
+  const bool aux = h->use_aux && h->aux && e.np > 0 && L - 2 > 2;
+  hipStream_t se = aux ? h->aux : st;
+  if (aux) {
+    MFS_HIP_TRY(hipEventRecord(h->ev_main, st));
+    MFS_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_main, 0));
+  }
   if (e.np > 0) {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(4 * h->cus, (plane_elems / VEC + kBlock - 1) / kBlock));
     if (j == 0)
-      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, true>), dim3(grid), dim3(kBlock), 0, st, (const T*)nullptr, (const T*)d_cur,
+      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, true>), dim3(grid), dim3(kBlock), 0, se, (const T*)nullptr, (const T*)d_cur,
                          (T*)nullptr, plane_elems, e, h->c.scal, p->dev, par, halo_tag);
     else
-      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, false>), dim3(grid), dim3(kBlock), 0, st, (const T*)h->c.r, (const T*)d_prev,
+      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, false>), dim3(grid), dim3(kBlock), 0, se, (const T*)h->c.r, (const T*)d_prev,
                          d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag);
     MFS_LAUNCH_CHECK();
   }
+  if (aux) MFS_HIP_TRY(hipEventRecord(h->ev_aux, h->aux));
   // 2. planes that touch no ghost, while the edge planes travel
   int n_part = 0;
   if (L - 2 > 2) {
@@ -562,7 +580,8 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     }
     n_part = grid;
   }
-  // 3. edge planes of q (ghost operands from the own window)
+  // 3. edge planes of q (ghost operands from the own window); needs this rank's own edge planes of d_j too
+  if (aux) MFS_HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
   if (e.np > 0) {
     const int64_t items = (int64_t)e.np * (h->Ny - 2) * (h->Nz / VEC);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (items + kApplyBlock - 1) / kApplyBlock));
@@ -588,6 +607,24 @@ int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p) {
     MFS_REQUIRE((size_t)h->Ny * h->Nz * h->c.elt == p->plane_bytes, "window plane size != Ny*Nz*sizeof(element)");
   }
   h->p2p = p;
+  if (p) {
+    // second stream for the edge-plane sends: the two cross-stream event hops cost ~16 us per iteration (measured on
+    // one GPU), the xGMI drain they hide grows with the plane -- default on from 1 MiB of granules per plane
+    // (bench.py calibrates the choice on the machine it runs on; MFS_SLAB_AUX_STREAM / mfs_pcg3d_slab_set_aux override)
+    if (h->use_aux < 0) h->use_aux = (p->world > 1 && 2 * p->plane_bytes >= (1u << 20)) ? 1 : 0;
+    return mfs_pcg3d_slab_set_aux(h, h->use_aux);
+  }
+  return MFS_OK;
+}
+
+int mfs_pcg3d_slab_set_aux(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->use_aux = on != 0;
+  if (h->use_aux && h->p2p && !h->aux) {
+    MFS_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    MFS_HIP_TRY(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    MFS_HIP_TRY(hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming));
+  }
   return MFS_OK;
 }
 
