@@ -1,7 +1,7 @@
 // mfs_p2p.h -- direct GPU-to-GPU exchange for the slab-decomposed CG (gfx950, xGMI).
 //
 // New design: the reference is single-GPU.  One process per GPU;
-// every rank owns a WINDOW of fine-grained device memory that its peers map through
+// every rank owns a WINDOW of uncached device memory that its peers map through
 // HIP IPC.  Inside the CG loop nothing but kernels touches it:
 //
 //   halo planes   the rank that owns an edge plane of the direction vector stores it
@@ -20,7 +20,7 @@
 // The only hardware property relied on is that an aligned 8-byte store is not torn.
 // Every wait is a bounded spin (wall clock); a timeout raises the engine's error word
 // and every later kernel of the solve returns at once, so a lost peer can never hang
-// the GPU.  All cross-GPU accesses are system-scope atomics / fences.
+// the GPU.  All cross-GPU accesses are system-scope (sc0 sc1) loads and stores on uncached memory.
 #pragma once
 #include "mfs_common.h"
 
@@ -35,7 +35,6 @@ constexpr size_t kP2pCtrlBytes = 8192;
 // Head of every rank's window.  Written ONLY by remote ranks (and zeroed once at creation).
 struct P2pCtrl {
   u64 ar[kArRing][kP2pMaxWorld][2];         // granules {tag << 32 | half} of rank r's contribution, episode ring
-  u64 test_flag[kP2pMaxWorld];              // self-test: token from each rank
 };
 static_assert(sizeof(P2pCtrl) <= kP2pCtrlBytes, "control block too large");
 
