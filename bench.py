@@ -206,13 +206,22 @@ def main():
                     if world > 1:
                         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                     return tt_.item() / C
-                eng.slab_set_aux(False)
-                t_p2p = probe(cg_p2p)
-                eng.slab_set_aux(True)                 # edge-plane sends from a second stream
-                t_p2p_aux = probe(cg_p2p)
+                healthy = True
+                try:
+                    eng.slab_set_aux(False)
+                    t_p2p = probe(cg_p2p)
+                    eng.poll()                             # raises if a peer-to-peer wait timed out
+                    eng.slab_set_aux(True)                 # edge-plane sends from a second stream
+                    t_p2p_aux = probe(cg_p2p)
+                    eng.poll()
+                except _lib.MfsError as exc:
+                    tinfo["p2p_error"] = str(exc)[:300]
+                    healthy = False
+                if not agree(healthy):                     # some rank lost a peer: everybody takes the collectives
+                    t_p2p = t_p2p_aux = float("inf")
                 t_rccl = probe(cg_rccl)
-                tinfo["calibration_ms_per_step"] = {"p2p": round(t_p2p * 1e3, 5), "p2p_aux_stream": round(t_p2p_aux * 1e3, 5),
-                                                    "rccl": round(t_rccl * 1e3, 5)}
+                r5 = lambda v: round(v * 1e3, 5) if v != float("inf") else None  # noqa: E731
+                tinfo["calibration_ms_per_step"] = {"p2p": r5(t_p2p), "p2p_aux_stream": r5(t_p2p_aux), "rccl": r5(t_rccl)}
                 eng.slab_set_aux(t_p2p_aux < t_p2p)
                 tinfo["p2p_aux_stream"] = bool(t_p2p_aux < t_p2p)
                 if min(t_p2p, t_p2p_aux) <= t_rccl:
