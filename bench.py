@@ -206,19 +206,24 @@ def main():
                     if world > 1:
                         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                     return tt_.item() / C
-                healthy = True
-                try:
-                    eng.slab_set_aux(False)
-                    t_p2p = probe(cg_p2p)
-                    eng.poll()                             # raises if a peer-to-peer wait timed out
+                def poll_ok():
+                    """collective: True only if NO rank saw a peer-to-peer wait time out"""
+                    try:
+                        eng.poll()
+                        good = True
+                    except _lib.MfsError as exc:
+                        tinfo["p2p_error"] = str(exc)[:300]
+                        good = False
+                    return agree(good)
+                t_p2p = t_p2p_aux = float("inf")
+                eng.slab_set_aux(False)
+                t = probe(cg_p2p)
+                if poll_ok():
+                    t_p2p = t
                     eng.slab_set_aux(True)                 # edge-plane sends from a second stream
-                    t_p2p_aux = probe(cg_p2p)
-                    eng.poll()
-                except _lib.MfsError as exc:
-                    tinfo["p2p_error"] = str(exc)[:300]
-                    healthy = False
-                if not agree(healthy):                     # some rank lost a peer: everybody takes the collectives
-                    t_p2p = t_p2p_aux = float("inf")
+                    t = probe(cg_p2p)
+                    if poll_ok():
+                        t_p2p_aux = t
                 t_rccl = probe(cg_rccl)
                 r5 = lambda v: round(v * 1e3, 5) if v != float("inf") else None  # noqa: E731
                 tinfo["calibration_ms_per_step"] = {"p2p": r5(t_p2p), "p2p_aux_stream": r5(t_p2p_aux), "rccl": r5(t_rccl)}
