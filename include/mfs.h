@@ -209,6 +209,9 @@ int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p);
  * The engine's grid is this rank's slab incl. one ghost / boundary plane each side.
  * A peer that does not answer within MFS_P2P_TIMEOUT_MS (default 3000) stops the solve:
  * the next poll / solve returns MFS_E_TIMEOUT.                                          */
+/* 1 if the slab loop can run on this engine (window attached, CG vectors bound and 16-byte aligned, Nz a multiple
+ * of the 16-byte vector length, stencil variant 2, pressure operator); else the caller uses the collective loop */
+int mfs_pcg3d_slab_supported(mfs_pcg3d* h);
 /* slab loop tuning: send the edge planes from a second HIP stream so that the xGMI stores overlap the interior
  * stencil launch (costs two cross-stream event hops per iteration; default: on for planes >= 1 MiB of granules) */
 int mfs_pcg3d_slab_set_aux(mfs_pcg3d* h, int on);

@@ -617,6 +617,12 @@ int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p) {
   return MFS_OK;
 }
 
+// 1 if the slab loop can run on this engine with the attached window (vector path, LDS march, bound aligned vectors)
+int mfs_pcg3d_slab_supported(mfs_pcg3d* h) {
+  if (!h || !h->c.x) return 0;
+  return slab_ok(h) ? 1 : 0;
+}
+
 int mfs_pcg3d_slab_set_aux(mfs_pcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
   h->use_aux = on != 0;

@@ -81,6 +81,7 @@ SIGNATURES = {
     "mfs_p2p_info": (_i, [_p, _pint, C.POINTER(_sz)]),
     "mfs_p2p_destroy": (_i, [_p]),
     "mfs_pcg3d_attach_p2p": (_i, [_p, _p]),
+    "mfs_pcg3d_slab_supported": (_i, [_p]),
     "mfs_pcg3d_slab_set_aux": (_i, [_p, _i]),
     "mfs_pcg3d_slab_begin": (_i, [_p, _d, _p]),
     "mfs_pcg3d_slab_iterate": (_i, [_p, _i64, _p]),

@@ -80,6 +80,7 @@ class SlabCG:
     def mode(self):
         return "p2p" if self.window is not None else ("rccl" if self.multi else "single")
 
+
     def _allreduce(self, slot):
         self.dist.all_reduce(self.ops.scalars[slot:slot + 1], group=self.group)
 
@@ -94,10 +95,17 @@ class SlabCG:
             ops.append(dist.P2POp(dist.irecv, d[self.L - 1], p.right, self.group))
         return dist.batch_isend_irecv(ops) if ops else []
 
+    def _p2p(self):
+        """the window is usable for the engine as bound right now (else: the collective loop, on every rank alike --
+        the conditions are properties of the grid and dtype, identical across ranks)"""
+        return self.window is not None and self.ops.slab_supported()
+
     def begin(self, tol):
-        if self.window is not None:
+        if self._p2p():
+            self._p2p_active = True
             self.ops.slab_begin(tol)
             return
+        self._p2p_active = False
         if not self.multi:
             self.ops.begin_local(tol)
             self.ops.begin_finish()
@@ -107,7 +115,7 @@ class SlabCG:
         self.ops.begin_finish()
 
     def iterate(self, n):
-        if self.window is not None:
+        if getattr(self, "_p2p_active", False):
             self.ops.slab_iterate(n)
             return
         if not self.multi:
@@ -149,8 +157,12 @@ class SlabCG:
     def solve(self, tol, max_iter, check_every=32):
         """begin + iterate until the device-resident `done` flag or max_iter; returns (converged, iterations).
         COLLECTIVE.  The scalars every rank tests are bit-identical, so all ranks leave the loop together."""
-        if self.window is not None:
+        if self._p2p():
+            self._p2p_active = True
             return self.ops.slab_solve(tol, max_iter, check_every)
+        self._p2p_active = False
+        if self.window is not None and self.dist is not None:
+            self.multi = True                  # a window was given but cannot be used: the collective loop
         if not self.multi:
             return self.ops.solve(tol, max_iter, check_every)
         self.begin(tol)

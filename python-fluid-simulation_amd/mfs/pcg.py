@@ -163,6 +163,9 @@ class PcgEngine:
                    "mfs_pcg3d_attach_p2p")
         self._window = window     # keep it alive while the engine points at it
 
+    def slab_supported(self):
+        return bool(self.lib.mfs_pcg3d_slab_supported(self.h))
+
     def slab_set_aux(self, on):
         _lib.check(self.lib.mfs_pcg3d_slab_set_aux(self.h, int(bool(on))), "mfs_pcg3d_slab_set_aux")
 

@@ -196,6 +196,7 @@ class SlabPressureCGSolver3D(PressureCGSolver3D):
             eng.setup(lphi, wx, wy, wz)
             eng.bind(self.buf.b, self.x, self.buf.d, self.buf.r, self.buf.q)
             ok, self.iterations = self._cg.solve(tol, self.max_iter, self.check_every)
+            self.transport = "p2p" if getattr(self._cg, "_p2p_active", False) else "rccl"   # what this solve actually used
             st = eng.poll()
             self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
             if not ok:
