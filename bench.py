@@ -121,9 +121,9 @@ def main():
     esz = 4 if args.dtype == "f32" else 8
     if args.n:
         n = args.n
-        ggrid = {1: (n, n, n), 2: (2 * n, n, n), 4: (2 * n, 2 * n, n), 8: (2 * n, 2 * n, 2 * n)}[world]
+        ggrid = {1: (n, n, n), 2: (2 * n, n, n), 4: (2 * n, 2 * n, n), 8: (2 * n, 2 * n, 2 * n)}.get(world, (n * world, n, n))
     else:
-        ggrid = GRIDS[world]
+        ggrid = GRIDS.get(world, (256 * world, 256, 256))      # other world sizes: 256 planes of 256^2 per rank
     if args.local_grid and world == 1:
         ggrid = tuple(int(v) for v in args.local_grid.split(","))
     seed = 0

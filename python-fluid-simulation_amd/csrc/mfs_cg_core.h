@@ -367,6 +367,7 @@ struct CgCore {
   int grid_vec = 2048, cus = 256;
   int64_t iter_enq = 0;        // iterations enqueued since begin (its parity selects the delta ring slot)
   int rev_xr = 0, rev_d = 0;   // sweep direction of the two vector phases (see for_each_vec)
+  int xr_vpt = 8;  // vectors per thread the x/r update aims for on small problems (MFS_XR_VEC_PER_THREAD)
   int nt_x = -1;   // nontemporal x stream in k_update_xr: 1 on, 0 off, -1 auto (working set > Infinity Cache)
   double* pinned = nullptr;
 };
@@ -396,6 +397,7 @@ static inline int core_init(CgCore& c, int dt, int64_t n) {
   }
   c.grid_vec = std::min(kMaxPartials, c.cus * env_int("MFS_VEC_BLOCKS_PER_CU", 8));
   c.nt_x = env_int("MFS_NT_X", -1);
+  c.xr_vpt = std::max(1, env_int("MFS_XR_VEC_PER_THREAD", 8));
   c.rev_xr = env_int("MFS_REV_XR", 0);
   c.rev_d = env_int("MFS_REV_D", 0);
   if (hipHostMalloc((void**)&c.pinned, MFS_PCG_NSCALARS * sizeof(double), hipHostMallocDefault) != hipSuccess) {
@@ -467,7 +469,7 @@ static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode 
   {   // >= 8 vectors per thread on small problems: fewer, fatter blocks (and fewer arrival tickets for a tail);
       // the same grid with or without a tail, so that the r.r partials group identically in both loop forms
     const int64_t per = vec ? (c.dt == MFS_F32 ? 4 : 2) : 1;
-    grid = std::max(1, (int)std::min<int64_t>(grid, std::max<int64_t>(c.cus, cnt / per / (kBlock * 8))));
+    grid = std::max(1, (int)std::min<int64_t>(grid, std::max<int64_t>(c.cus, cnt / per / (kBlock * c.xr_vpt))));
   }
   const bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
   if (mode == 1) { MFS_XR_MODE(1) } else if (mode == 2) { MFS_XR_MODE(2) } else { MFS_XR_MODE(0) }
