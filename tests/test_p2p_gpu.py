@@ -62,6 +62,8 @@ def _run_ranks(name, world, tmp_path, dtname, solves=1, **extra_env):
 @pytest.mark.parametrize("name,world,dtname", [
     ("p3d_e_allfluid_12", 1, "f64"), ("p3d_e_allfluid_12", 2, "f64"), ("p3d_d_20", 2, "f64"), ("p3d_d_20", 3, "f64"),
     ("p3d_d_20", 2, "f32"),
+    ("p3d_a_12", 5, "f64"),          # two owned planes per rank: both are edge planes, no interior launch
+    ("p3d_d_20", 5, "f64"),          # uneven slabs (4,4,3,4,3 owned planes), three ranks with two neighbours
 ])
 def test_slab_p2p_matches_single_domain(name, world, dtname, tmp_path):
     g = golden(name)
