@@ -207,7 +207,7 @@ int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p);
 /* the slab loop: begin / iterate / solve with the semantics of mfs_pcg3d_begin / _iterate /
  * _solve on the GLOBAL grid; COLLECTIVE -- every rank of the window calls them in step.
  * The engine's grid is this rank's slab incl. one ghost / boundary plane each side.
- * A peer that does not answer within MFS_P2P_TIMEOUT_MS (default 3000) stops the solve:
+ * A peer that does not answer within MFS_P2P_TIMEOUT_MS (default 10000) stops the solve:
  * the next poll / solve returns MFS_E_TIMEOUT.                                          */
 /* 1 if the slab loop can run on this engine (window attached, CG vectors bound and 16-byte aligned, Nz a multiple
  * of the 16-byte vector length, stencil variant 2, pressure operator); else the caller uses the collective loop */

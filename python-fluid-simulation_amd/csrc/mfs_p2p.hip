@@ -82,7 +82,7 @@ static void p2p_fill_dev(P2pHost& p) {
     if (p.rank > 0) d.send[0][q] = buf(p.peer_window[p.rank - 1], 1, q);            // my plane 1 = left neighbour's HIGH ghost
     if (p.rank < p.world - 1) d.send[1][q] = buf(p.peer_window[p.rank + 1], 0, q);  // my plane L-2 = right neighbour's LOW ghost
   }
-  const int ms = std::max(1, env_int("MFS_P2P_TIMEOUT_MS", 3000));
+  const int ms = std::max(1, env_int("MFS_P2P_TIMEOUT_MS", 10000));
   d.timeout_ticks = (u64)ms * 100000ull;   // wall_clock64 ticks at 100 MHz
 }
 
