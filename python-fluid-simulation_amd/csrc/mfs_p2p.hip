@@ -83,7 +83,13 @@ static void p2p_fill_dev(P2pHost& p) {
     if (p.rank < p.world - 1) d.send[1][q] = buf(p.peer_window[p.rank + 1], 0, q);  // my plane L-2 = right neighbour's LOW ghost
   }
   const int ms = std::max(1, env_int("MFS_P2P_TIMEOUT_MS", 10000));
-  d.timeout_ticks = (u64)ms * 100000ull;   // wall_clock64 ticks at 100 MHz
+  int dev = 0, khz = 0;                     // wall_clock64() rate of this device (100 MHz on MI300-class parts)
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess ||
+      khz <= 0) {
+    (void)hipGetLastError();
+    khz = 100000;
+  }
+  d.timeout_ticks = (u64)ms * (u64)khz;
 }
 
 }  // namespace mfs
