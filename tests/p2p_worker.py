@@ -48,6 +48,35 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if os.environ.get("P2P_TEST_MODE") == "lost_peer":
+        # fault injection: rank 1 maps its window and then never takes part in the solve
+        from mfs import _lib
+        import time as _t
+        try:
+            lg = (8, 12, 8)
+            win = P2PWindow(dist, lg[1] * lg[2] * 8, dev)
+            assert win.ok, win.why
+            if rank == 0:
+                eng = PcgEngine(lg, torch.float64, dev)
+                one = lambda *sh: torch.ones(sh, dtype=torch.float64, device=dev)  # noqa: E731
+                eng.setup(-one(*lg), one(lg[0] + 1, lg[1], lg[2]), one(lg[0], lg[1] + 1, lg[2]), one(lg[0], lg[1], lg[2] + 1))
+                b, x, d, r, q = one(*lg), *(torch.zeros(lg, dtype=torch.float64, device=dev) for _ in range(4))
+                eng.bind(b, x, d, r, q)
+                cg = SlabCG(eng, SlabPartition(14, 2, 0), d, dist, window=win)
+                t0 = _t.perf_counter()
+                cg.begin(1e-9)
+                cg.iterate(8)
+                try:
+                    eng.poll()
+                    outcome = "no error"
+                except _lib.MfsError as exc:
+                    outcome = "MfsError: " + str(exc)
+                with open(f"{out}.rank0.txt", "w") as f:
+                    f.write(f"{_t.perf_counter() - t0:.3f}\n{outcome}\n")
+            win.close()
+        finally:
+            dist.destroy_process_group()
+        return
     if os.environ.get("P2P_TEST_MODE") == "solver":
         try:
             solver_mode(rank, world, path, out, dtname, dev)

@@ -137,3 +137,18 @@ def test_slab_solver_class_rccl_style_loop_over_gloo(tmp_path):
     assert all(str(r["transport"]) == "rccl" for r in res)
     assert int(res[0]["iters"]) == int(g["iters"])
     np.testing.assert_allclose(res[0]["hist"], g["history"], rtol=1e-9)
+
+
+def test_lost_peer_is_reported_not_hung(tmp_path):
+    """fault injection: the neighbour never joins the solve -> every wait gives up after MFS_P2P_TIMEOUT_MS, later
+    kernels return at their top, and the next poll raises with status MFS_E_TIMEOUT (-4)."""
+    port = _free_port()
+    out = str(tmp_path / "lost")
+    env = dict(os.environ, MFS_P2P_TIMEOUT_MS="400", P2P_TEST_MODE="lost_peer")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", str(port), "-", out, "f64"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+    secs, outcome = open(out + ".rank0.txt").read().strip().split("\n")
+    assert outcome.startswith("MfsError") and "status -4" in outcome and "timed out" in outcome, outcome
+    assert float(secs) < 20.0
