@@ -167,6 +167,10 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
  * coefficient arrays only for z-vectors that are neither all-zero rows nor regular
  * interior rows (class byte per vector built by mfs_pcg3d_setup); results are bit-identical */
 int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
+/* OPT-IN Jacobi preconditioning of the native loop (default off; env MFS_JACOBI=1): z = r / diag fused into the
+ * two vector phases, delta = r.z, convergence test unchanged (r.r < tol^2).  NOT the reference's algorithm -- the
+ * reference's CG is unpreconditioned and its residual history cannot be matched with this on.  One GPU only.  */
+int mfs_pcg3d_set_jacobi(mfs_pcg3d* h, int on);
 /* fused direction update (default on, native loop only): `d = r + beta d` is formed inside the next
  * stencil launch instead of in a pass of its own; bit-identical; d ping-pongs with an engine buffer */
 int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on);

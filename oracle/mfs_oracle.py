@@ -1072,3 +1072,59 @@ def sdf_project(rb_d, position):
                     pos = _sdf_to_world(rb, prb)
             pos = pos.astype(position.dtype).astype(F64)     # the reference writes into the array row
         position[p] = pos
+
+
+# =============================================================================
+# opt-in Jacobi-preconditioned CG (an EXTRA of the MI355X build, csrc/mfs_pcg.hip "optional Jacobi
+# preconditioning"; the reference's CG is unpreconditioned).  Oracle of that extra only.
+# =============================================================================
+def pressure_diag3d(gres, wx, wy, wz, lphi):
+    """the diagonal of the pressure operator (the `diag` accumulated in solver/PressureCGSolver3D.py:59-126);
+    0 on boundary and non-fluid cells."""
+    Nx, Ny, Nz = (int(g) for g in gres)
+    out = np.zeros((Nx, Ny, Nz))
+    if min(Nx, Ny, Nz) < 3:
+        return out
+    sh = lambda a, dx, dy, dz: np.asarray(a, F64)[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy, 1 + dz:Nz - 1 + dz]  # noqa: E731
+    phi = sh(lphi, 0, 0, 0)
+    diag = np.zeros_like(phi)
+    for off, w in (((1, 0, 0), sh(wx, 1, 0, 0)), ((-1, 0, 0), sh(wx, 0, 0, 0)), ((0, 1, 0), sh(wy, 0, 1, 0)),
+                   ((0, -1, 0), sh(wy, 0, 0, 0)), ((0, 0, 1), sh(wz, 0, 0, 1)), ((0, 0, -1), sh(wz, 0, 0, 0))):
+        nphi = sh(lphi, *off)
+        diag = diag + np.where(nphi < 0, w, w / _theta(phi, nphi))
+    out[1:-1, 1:-1, 1:-1] = np.where(phi < 0, diag, 0.0)
+    return out
+
+
+def cg_jacobi(apply, diag, b, x, d, r, q, tol, max_iter, history=None):
+    """Jacobi-preconditioned CG with the reference's stopping rule (r.r < tol^2 after the x / r update):
+    z = r / diag (0 where diag = 0), delta = r.z.  history = [rr0, dq1, rr1, ...] like `cg`."""
+    zof = lambda rv: np.divide(rv, diag, out=np.zeros_like(rv), where=diag != 0)  # noqa: E731
+    x *= 0.0
+    apply((x,), (q,))
+    r[...] = b - q
+    d[...] = zof(r)
+    rr = float(np.sum(r * r))
+    delta = float(np.sum(r * d))
+    if history is not None:
+        history.append(rr)
+    it = 0
+    if not rr < tol ** 2:
+        for it in range(1, int(max_iter) + 1):
+            apply((d,), (q,))
+            dq = float(np.sum(d * q))
+            alpha = delta / dq
+            x += alpha * d
+            r -= alpha * q
+            z = zof(r)
+            rr, rz = float(np.sum(r * r)), float(np.sum(r * z))
+            if history is not None:
+                history.extend((dq, rr))
+            if rr < tol ** 2:
+                break
+            beta = rz / delta
+            delta = rz
+            d[...] = z + beta * d
+        else:
+            raise ValueError("Failed to converge!")
+    return it, rr

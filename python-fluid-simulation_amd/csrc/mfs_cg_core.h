@@ -41,6 +41,7 @@ constexpr int64_t kHistCap = 16384;
 enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TOL2 = MFS_PCG_S_TOL2,
        S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
        S_LASTRR = MFS_PCG_S_LASTRR, S_RING = 9 /* 2 slots: delta by iteration parity */,
+       S_RZ = 12 /* Jacobi loop: r.z of the latest update */,
        S_ERR = MFS_PCG_S_ERR /* != 0: a peer-to-peer wait timed out (slab loop); the solve is stopped */ };
 
 

@@ -64,6 +64,119 @@ k_pcg_setup(int Nx, int Ny, int Nz, const void* lphi, int ldt, const void* wx, c
   diag[i] = (T)dg;
 }
 
+// ------------------------------------------------- optional Jacobi preconditioning -----
+// NOT the reference's algorithm (its CG is unpreconditioned, SURVEY.md "three facts" 3): an opt-in extra
+// (mfs_pcg3d_set_jacobi) for callers that want fewer iterations and do not need the reference's residual
+// history.  z = r / diag is never stored: it is formed where it is consumed, so the preconditioner is fused
+// into the two vector phases (one extra read of `diag` each).  delta = r.z drives alpha and beta; the
+// convergence test stays the reference's r.r < tol^2.  Three launches per iteration: stencil, x/r update,
+// direction update; dot products folded into their consumers as in the plain loop.
+__device__ __forceinline__ double jac_z(double r, double dg) { return dg != 0.0 ? r / dg : 0.0; }
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_jac_init(const T* __restrict__ b, const T* __restrict__ q, const T* __restrict__ diag, T* __restrict__ d,
+           T* __restrict__ r, int64_t n, double* __restrict__ part_rr, double* __restrict__ part_rz) {
+  double arr = 0.0, arz = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const T rv = (T)((double)b[i] - (double)q[i]);
+    const double z = jac_z((double)rv, (double)diag[i]);
+    r[i] = rv;
+    d[i] = (T)z;
+    arr += (double)rv * (double)rv;
+    arz += (double)rv * z;
+  }
+  const double t1 = block_sum<kBlock>(arr);
+  const double t2 = block_sum<kBlock>(arz);
+  if (threadIdx.x == 0) { part_rr[blockIdx.x] = t1; part_rz[blockIdx.x] = t2; }
+}
+
+static __global__ void k_jac_begin_finish(double* scal, double* hist) {
+  if (threadIdx.x == 0) {
+    const double rr = scal[S_RR], rz = scal[S_RZ];
+    scal[S_DELTA] = rz;
+    scal[S_RING + 0] = rz;
+    scal[S_LASTRR] = rr;
+    hist[0] = rr;
+    if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0;
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_jac_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q,
+                const T* __restrict__ diag, int64_t n, double* __restrict__ scal, double* __restrict__ part_rr,
+                double* __restrict__ part_rz, int par, const double* __restrict__ part_dq, int npart) {
+  if (scal[S_DONE] != 0.0) return;
+  const double dq = block_total_of(part_dq, npart);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
+  const double alpha = scal[S_RING + par] / dq;
+  double arr = 0.0, arz = 0.0;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      vec_t<T, VEC> xv = vload<T, VEC>(x + i), rv = vload<T, VEC>(r + i);
+      const vec_t<T, VEC> dv = vload<T, VEC>(d + i), qv = vload<T, VEC>(q + i), gv = vload<T, VEC>(diag + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
+        rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
+        arr += (double)rv[j] * (double)rv[j];
+        arz += (double)rv[j] * jac_z((double)rv[j], (double)gv[j]);
+      }
+      vstore<T, VEC>(x + i, xv);
+      vstore<T, VEC>(r + i, rv);
+    } else {
+      x[i] = (T)((double)x[i] + alpha * (double)d[i]);
+      const T rn = (T)((double)r[i] - alpha * (double)q[i]);
+      r[i] = rn;
+      arr += (double)rn * (double)rn;
+      arz += (double)rn * jac_z((double)rn, (double)diag[i]);
+    }
+  });
+  const double t1 = block_sum<kBlock>(arr);
+  const double t2 = block_sum<kBlock>(arz);
+  if (threadIdx.x == 0) { part_rr[blockIdx.x] = t1; part_rz[blockIdx.x] = t2; }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__ diag, int64_t n,
+               double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
+               const double* __restrict__ part_rr, const double* __restrict__ part_rz, int npart) {
+  if (scal[S_DONE] != 0.0) return;
+  const double rr = block_total_of(part_rr, npart);
+  const double rz = block_total_of(part_rz, npart);
+  const double delta = scal[S_RING + par];
+  const bool conv = rr < scal[S_TOL2];
+  const double beta = rz / delta;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double dq = scal[S_DQ];
+    const int64_t it = (int64_t)scal[S_ITERS];
+    if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+    scal[S_ITERS] = (double)(it + 1);
+    scal[S_RING + (par ^ 1)] = rz;
+    scal[S_RR] = rr;
+    scal[S_RZ] = rz;
+    scal[S_DELTA] = delta;
+    scal[S_LASTRR] = rr;
+    scal[S_ALPHA] = delta / dq;
+    if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
+  }
+  if (conv) return;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      vec_t<T, VEC> dv = vload<T, VEC>(d + i);
+      const vec_t<T, VEC> rv = vload<T, VEC>(r + i), gv = vload<T, VEC>(diag + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dv[j] = (T)(jac_z((double)rv[j], (double)gv[j]) + beta * (double)dv[j]);
+      vstore<T, VEC>(d + i, dv);
+    } else {
+      d[i] = (T)(jac_z((double)r[i], (double)diag[i]) + beta * (double)d[i]);
+    }
+  });
+}
+
 }  // namespace mfs
 
 using namespace mfs;
@@ -75,6 +188,8 @@ struct mfs_pcg3d {
   char* ws;
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
+  int jacobi;                  // 1: opt-in Jacobi-preconditioned loop (mfs_pcg3d_set_jacobi); NOT the reference's CG
+  double* part_rz;             // partial sums of r.z (Jacobi loop)
   void* cz2;                   // asym only: weight of the -z tap (the density operator, DensityCGSolver3D.py:184)
   int asym;                    // 1: set up by mfs_pcg3d_setup_density
   void* d2;                    // ping-pong partner of the bound d (fused direction update)
@@ -198,7 +313,8 @@ extern "C" {
 size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   const int64_t n = gres[0] * gres[1] * gres[2];
-  return core_ws_bytes() + 6 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096);
+  return core_ws_bytes() + 6 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096) +
+         align_up((size_t)kMaxPartials * 8, 4096);
 }
 
 int64_t mfs_pcg3d_history_capacity(void) { return kHistCap; }
@@ -223,6 +339,8 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->cz2 = p + 5 * cs;
   h->asym = 0;
   h->cls = (unsigned char*)(p + 6 * cs);
+  h->part_rz = (double*)(p + 6 * cs + align_up((size_t)h->n, 4096));
+  h->jacobi = env_int("MFS_JACOBI", 0);
   h->fuse = env_int("MFS_FUSE_D", 1);
   h->pd = env_int("MFS_APPLY_PD", 1);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
@@ -343,6 +461,12 @@ int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on) {
   return MFS_OK;
 }
 
+int mfs_pcg3d_set_jacobi(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->jacobi = on != 0;
+  return MFS_OK;
+}
+
 int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
   h->compress = on != 0;
@@ -417,7 +541,52 @@ int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream) {
   return core_begin_finish(h->c, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+static int jac_begin(mfs_pcg3d* h, double tol, hipStream_t st) {
+  if (int e = core_begin_pre(h->c, tol, true, st)) return e;
+  int grid = 0;
+  if (int e = apply_dispatch(h, h->c.x, h->c.q, 1, h->Nx - 1, h->c.part_dq, 0, st, &grid)) return e;
+  const int g2 = std::max(1, (int)std::min<int64_t>(h->c.grid_vec, (h->n + kBlock - 1) / kBlock));
+  if (h->dt == MFS_F32)
+    hipLaunchKernelGGL((k_jac_init<float>), dim3(g2), dim3(kBlock), 0, st, (const float*)h->c.b, (const float*)h->c.q,
+                       (const float*)h->diag, (float*)h->c.d, (float*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+  else
+    hipLaunchKernelGGL((k_jac_init<double>), dim3(g2), dim3(kBlock), 0, st, (const double*)h->c.b, (const double*)h->c.q,
+                       (const double*)h->diag, (double*)h->c.d, (double*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+  MFS_LAUNCH_CHECK();
+  h->c.n_part_rr = g2;
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st, h->c.part_rr, g2, h->c.scal, (int)S_RR, 0);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st, h->part_rz, g2, h->c.scal, (int)S_RZ, 0);
+  hipLaunchKernelGGL(k_jac_begin_finish, dim3(1), dim3(64), 0, st, h->c.scal, h->c.hist);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+template <typename T, int VEC>
+static int jac_iteration(mfs_pcg3d* h, hipStream_t st) {
+  if (int e = mfs_pcg3d_phase_apply(h, 1, h->Nx - 1, 1, st)) return e;      // q = A d, d.q partials
+  const bool vec = VEC > 1;
+  const int grid = core_vec_grid(h->c, vec);
+  const int par = (int)(h->c.iter_enq & 1);
+  hipLaunchKernelGGL((k_jac_update_xr<T, VEC>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)h->c.d, (T*)h->c.r,
+                     (const T*)h->c.q, (const T*)h->diag, h->n, h->c.scal, h->c.part_rr, h->part_rz, par, h->c.part_dq,
+                     h->c.n_part_dq);
+  hipLaunchKernelGGL((k_jac_update_d<T, VEC>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.d, (const T*)h->c.r,
+                     (const T*)h->diag, h->n, h->c.scal, h->c.hist, kHistCap, par, h->c.part_rr, h->part_rz, grid);
+  MFS_LAUNCH_CHECK();
+  h->c.n_part_rr = grid;
+  ++h->c.iter_enq;
+  return MFS_OK;
+}
+
+extern "C" {
+
 int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
+  if (h && h->jacobi) {
+    MFS_REQUIRE(h->c.x && h->is_setup, "engine not bound / set up");
+    return jac_begin(h, tol, (hipStream_t)stream);
+  }
   if (int e = mfs_pcg3d_begin_local(h, tol, stream)) return e;
   return mfs_pcg3d_begin_finish(h, stream);
 }
@@ -425,7 +594,7 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
 static bool native_fuse_ok(const mfs_pcg3d* h) {
   const bool vec_in = h->vec_ok && ((uintptr_t)h->c.d % 16 == 0) && ((uintptr_t)h->c.q % 16 == 0) &&
                       ((uintptr_t)h->c.r % 16 == 0);
-  return h->fuse != 0 && h->variant == 2 && vec_in && h->Ny >= 3 && h->Nz >= 3 && h->Nx >= 3;
+  return h->fuse != 0 && !h->jacobi && h->variant == 2 && vec_in && h->Ny >= 3 && h->Nz >= 3 && h->Nx >= 3;
 }
 
 // the stencil launch of native iteration j = iter_enq: plain for j = 0, else with d_j = r + beta d_{j-1}
@@ -464,6 +633,16 @@ int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
 
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  if (h->jacobi) {
+    const bool vec = core_vec_ok(h->c) && ((uintptr_t)h->diag % 16 == 0);
+    for (int64_t i = 0; i < n; ++i) {
+      int e;
+      if (h->dt == MFS_F32) e = vec ? jac_iteration<float, 4>(h, (hipStream_t)stream) : jac_iteration<float, 1>(h, (hipStream_t)stream);
+      else e = vec ? jac_iteration<double, 2>(h, (hipStream_t)stream) : jac_iteration<double, 1>(h, (hipStream_t)stream);
+      if (e) return e;
+    }
+    return MFS_OK;
+  }
   for (int64_t i = 0; i < n; ++i) {   // 3 launches per iteration: the dots are folded into their consumers
     int e;
     if ((e = mfs_pcg3d_native_apply(h, stream))) return e;
@@ -529,7 +708,7 @@ int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_strea
 // Slab loop over peer-to-peer windows (mfs_pcg_slab.h): one rank of a grid cut into x-slabs.
 // ----------------------------------------------------------------------------------------------
 static bool slab_ok(const mfs_pcg3d* h) {
-  return h->p2p && h->p2p->connected && native_fuse_ok(h) && !h->asym &&
+  return h->p2p && h->p2p->connected && native_fuse_ok(h) && !h->asym && !h->jacobi &&
          (size_t)h->Ny * h->Nz * h->c.elt == h->p2p->plane_bytes;
 }
 

@@ -52,6 +52,10 @@ class PcgEngine:
     def set_fuse(self, on):
         _lib.check(self.lib.mfs_pcg3d_set_fuse(self.h, int(bool(on))), "mfs_pcg3d_set_fuse")
 
+    def set_jacobi(self, on):
+        """opt-in Jacobi preconditioning (NOT the reference's CG: fewer iterations, different residual history)"""
+        _lib.check(self.lib.mfs_pcg3d_set_jacobi(self.h, int(bool(on))), "mfs_pcg3d_set_jacobi")
+
     def set_compress(self, on):
         _lib.check(self.lib.mfs_pcg3d_set_compress(self.h, int(bool(on))), "mfs_pcg3d_set_compress")
 

@@ -86,7 +86,9 @@ class PressureCGSolver3D:
     enqueued between host looks at the device-resident convergence flag.
     """
 
-    def __init__(self, buf, gres, bound_size, check_every=32):
+    def __init__(self, buf, gres, bound_size, check_every=32, jacobi=None):
+        """`jacobi=True` (or MFS_JACOBI=1) switches on the build's opt-in Jacobi preconditioner: fewer iterations,
+        same stopping rule -- but no longer the reference's iteration (its CG is unpreconditioned)."""
         self.gres = gres
         self._g = T.as_gres(gres)
         if len(self._g) != 3:
@@ -105,6 +107,8 @@ class PressureCGSolver3D:
         self.check_every = int(check_every)
         self.iterations = 0
         self._engine = PcgEngine(self._g, dt, device)
+        if jacobi is not None:
+            self._engine.set_jacobi(jacobi)
 
     @property
     def history(self):
