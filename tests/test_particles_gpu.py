@@ -90,3 +90,31 @@ def test_transfers_feed_the_solvers():
     x0 = p.x.clone()
     ds.solve(1000.0, float(d["dt"]), p.x, p.m, p.vol, None, None, None, sphi, sv, ls.phi, lvol)
     assert ds.iterations > 0 and torch.isfinite(p.x).all() and not torch.equal(p.x, x0)
+
+
+def test_empty_particle_sets_and_misuse():
+    """zero particles are a no-op everywhere (the reference launches zero blocks); wrong shapes fail loudly"""
+    gres = (6, 7, 8)
+    bmin, bsz = np.zeros(3, np.float32), np.asarray(gres, np.float32) * 0.1
+    eye = np.eye(3, dtype=int)
+    comp = lambda a, b: NS(bias=np.asarray(b, np.float32), m=torch.zeros(tuple(np.array(gres) + eye[a]), dtype=torch.float32, device=DEV),  # noqa: E731
+                           v=torch.ones(tuple(np.array(gres) + eye[a]), dtype=torch.float32, device=DEV))
+    grid = NS(resolution=gres, bound_min=bmin, bound_size=bsz, cell_size=bsz / np.asarray(gres, np.int64), x=comp(0, [0, .5, .5]),
+              y=comp(1, [.5, 0, .5]), z=comp(2, [.5, .5, 0]))
+    e3 = lambda: torch.zeros((0, 3), dtype=torch.float64, device=DEV)  # noqa: E731
+    p = NS(num_particles=0, x=e3(), m=torch.zeros(0, dtype=torch.float64, device=DEV), v=e3(), cx=e3(), cy=e3(), cz=e3(), vol=1e-3)
+    K.p2g(p, grid)
+    K.g2p(p, grid)
+    assert float(grid.x.m.abs().max()) == 0.0 and float(grid.x.v.min()) == 1.0      # untouched
+    ls = NS(resolution=gres, bound_min=bmin, bound_size=bsz, cell_size=grid.cell_size, phi=torch.zeros(gres, dtype=torch.float64, device=DEV))
+    K.compute_fluid_levelset(p, ls, 0.1)
+    assert torch.allclose(ls.phi, torch.full_like(ls.phi, 0.3))                      # the pre-fill gdx * 3 everywhere
+    vres = tuple(2 * np.array(gres) + 1)
+    fv = NS(resolution=vres, bound_min=bmin, bound_size=bsz, cell_size=bsz / (2 * np.asarray(gres, np.int64)),
+            vol=torch.ones(vres, dtype=torch.float64, device=DEV))
+    K.compute_fluid_volume(p, fv, p.vol)
+    assert float(fv.vol.abs().max()) == 0.0
+    with pytest.raises(ValueError, match="shape"):
+        K.p2g(NS(num_particles=2, x=torch.zeros((2, 2), dtype=torch.float64, device=DEV), m=p.m, v=p.v, cx=p.cx, cy=p.cy, cz=p.cz), grid)
+    with pytest.raises(TypeError, match="GPU"):
+        K.compute_fluid_levelset(NS(x=torch.zeros((1, 3), dtype=torch.float64)), ls, 0.1)

@@ -78,3 +78,17 @@ def test_cylinder_against_the_restatement():
     S.project(rb_d, proj)
     O.sdf_project(N(rb_d), rproj)
     np.testing.assert_allclose(N(proj), rproj, rtol=0, atol=1e-14)
+
+
+def test_no_bodies_and_misuse():
+    """evaluate with an empty scene: every distance is the reference's initial 100, velocities 0; project: no-op"""
+    rb = torch.zeros((0, 10, 4), dtype=torch.float64, device=DEV)
+    pos = torch.rand((50, 3), dtype=torch.float64, device=DEV)
+    sd, vel = torch.zeros(50, dtype=torch.float64, device=DEV), torch.ones((50, 3), dtype=torch.float64, device=DEV)
+    S.evaluate(rb, sd, vel, pos)
+    assert float(sd.min()) == 100.0 and float(vel.abs().max()) == 0.0
+    before = pos.clone()
+    S.project(rb, pos)
+    assert torch.equal(pos, before)
+    with pytest.raises(ValueError, match="rb_d"):
+        S.project(torch.zeros((1, 9, 4), dtype=torch.float64, device=DEV), pos)
