@@ -310,6 +310,21 @@ def main():
             torch.cuda.synchronize()
             ms_b2b = s_ev.elapsed_time(e_ev) / reps
         achieved = alg_bytes / (ms_cg * 1e-3) / 1e9
+        # the same measurement on the PLAIN stencil apply (6N^3 + 3N^2 scalars -- the figure
+        # BASELINE.md's 60 % target is stated on), inside the three-kernel form of the loop (direction update unfused)
+        eng.set_fuse(False)
+        eng.begin(0.0)
+        eng.iterate(2)
+        alg_plain = (6 * Nx * Ny * Nz + 3 * Ny * Nz) * esz
+        evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for s_ev, e_ev in evp:
+            s_ev.record()
+            eng.native_apply()
+            e_ev.record()
+            eng.native_finish()
+        torch.cuda.synchronize()
+        ms_plain = sum(s.elapsed_time(e) for s, e in evp) / reps
+        eng.set_fuse(True)
         traffic = None
         # HBM bytes per launch from PMC counters: collected by tools/pmc_bench.sh on this same command
         # (separate rocprofv3 --pmc passes) and committed under profiles/; valid for the default workload only
@@ -325,6 +340,10 @@ def main():
               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
               "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5),
               "kernel_ms_raw_events": round(ms_raw, 5), "event_pair_overhead_ms": round(ev_over, 5)}
+        rf["plain_stencil_apply"] = {"kernel": "k_pcg_apply_march<..., FUSE=false> (6N^3+3N^2 scalars, SURVEY.md 8(d))",
+                                     "algorithmic_bytes": alg_plain, "kernel_ms": round(ms_plain, 5),
+                                     "achieved": round(alg_plain / (ms_plain * 1e-3) / 1e9, 1),
+                                     "frac": round(alg_plain / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if ms_b2b:
             rf["kernel_ms_back_to_back"] = round(ms_b2b, 5)
             rf["achieved_back_to_back"] = round(alg_bytes / (ms_b2b * 1e-3) / 1e9, 1)
