@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--n", type=int, default=0, help="override: cubic grid edge per GPU (default 256)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the 256^3 grid is split over the ranks instead of 256^3 per rank")
     ap.add_argument("--local-grid", default="", help="1 GPU experiments: Nx,Ny,Nz of the grid (e.g. 66,512,512 = one rank's slab of the 8-GPU run)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,6 +125,9 @@ def main():
         ggrid = {1: (n, n, n), 2: (2 * n, n, n), 4: (2 * n, 2 * n, n), 8: (2 * n, 2 * n, 2 * n)}.get(world, (n * world, n, n))
     else:
         ggrid = GRIDS.get(world, (256 * world, 256, 256))      # other world sizes: 256 planes of 256^2 per rank
+    if args.strong:
+        n = args.n or 256
+        ggrid = (n, n, n)
     if args.local_grid and world == 1:
         ggrid = tuple(int(v) for v in args.local_grid.split(","))
     seed = 0
@@ -361,7 +365,7 @@ def main():
             "metric": "PressureCGSolver3D CG throughput (cells x iterations / s)",
             "value": round(value, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"PressureCGSolver3D {ggrid[0]}x{ggrid[1]}x{ggrid[2]} synthetic pool scene, "
                                    f"fp32 state" if args.dtype == "f32" else
                                    f"PressureCGSolver3D {ggrid[0]}x{ggrid[1]}x{ggrid[2]} synthetic pool scene, fp64 state",
