@@ -249,16 +249,20 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
 }
 
 // convergence test (:218), bookkeeping, beta (:220), d = r + beta d (:221)
-template <typename T, int VEC>
+// XUPD: this kernel also does `x += alpha d` (:212) -- the x update rides here instead of in k_update_xr (MODE 1
+// there), because d is already being read: 3 + 5 instead of 6 + 3 scalars per DOF for the two vector phases.
+// The values are the same (x_j + alpha_j d_j with the same alpha); on the converging iteration only x is updated.
+template <typename T, int VEC, bool XUPD = false>
 __global__ void __launch_bounds__(kBlock)
 k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __restrict__ scal,
            double* __restrict__ hist, int64_t hist_cap, int rev, int par, const double* __restrict__ part_rr,
-           int npart) {
+           int npart, T* __restrict__ x = nullptr) {
   if (scal[S_DONE] != 0.0) return;
   const double rr = npart > 0 ? block_total_of(part_rr, npart) : scal[S_RR];
   const double delta = scal[S_RING + par], tol2 = scal[S_TOL2];
   const bool conv = rr < tol2;
   const double beta = rr / delta;
+  const double alpha_x = XUPD ? delta / scal[S_DQ] : 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const double dq = scal[S_DQ];
     const int64_t it = (int64_t)scal[S_ITERS];     // only this thread ever writes ITERS
@@ -271,15 +275,24 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
     scal[S_ALPHA] = delta / dq;
     if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
   }
-  if (conv) return;
+  if (conv && !XUPD) return;
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
     if (vec) {
       Vec<T, VEC> dv = ldv<T, VEC>(d + i);
+      if (XUPD) {
+        Vec<T, VEC> xv = ldv<T, VEC>(x + i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xv.v[j] = (T)((double)xv.v[j] + alpha_x * (double)dv.v[j]);
+        *reinterpret_cast<Vec<T, VEC>*>(x + i) = xv;
+        if (conv) return;
+      }
       const Vec<T, VEC> rv = ldv<T, VEC>(r + i);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) dv.v[j] = (T)((double)rv.v[j] + beta * (double)dv.v[j]);
       *reinterpret_cast<Vec<T, VEC>*>(d + i) = dv;
     } else {
+      if (XUPD) x[i] = (T)((double)x[i] + alpha_x * (double)d[i]);
+      if (conv) return;
       d[i] = (T)((double)r[i] + beta * (double)d[i]);
     }
   }, rev != 0);
@@ -481,10 +494,22 @@ static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode 
 #undef MFS_XR_MODE
 #undef MFS_XR
 
-static inline int core_update_d(CgCore& c, bool fold, hipStream_t st) {
+// xupd: the kernel also performs x += alpha d (pair it with core_update_xr mode 1)
+static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd = false) {
   MFS_REQUIRE(c.d, "engine not bound");
   const bool vec = core_vec_ok(c);
   const int grid = core_vec_grid(c, vec);
+  if (xupd) {
+#define MFS_UD(TT, VV) \
+    hipLaunchKernelGGL((k_update_d<TT, VV, true>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
+                       c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x)
+    if (c.dt == MFS_F32) { if (vec) MFS_UD(float, 4); else MFS_UD(float, 1); }
+    else                 { if (vec) MFS_UD(double, 2); else MFS_UD(double, 1); }
+#undef MFS_UD
+    MFS_LAUNCH_CHECK();
+    ++c.iter_enq;
+    return MFS_OK;
+  }
   if (c.dt == MFS_F32) {
     if (vec) hipLaunchKernelGGL((k_update_d<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0);
     else hipLaunchKernelGGL((k_update_d<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)c.d, (const float*)c.r, c.n, c.scal, c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0);

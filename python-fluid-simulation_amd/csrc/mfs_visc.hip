@@ -584,6 +584,7 @@ struct mfs_vcg3d {
   int tiled;     // 1: CG applies use the LDS-staged kernel (default); 0: the direct-load fused kernel
   int xchunk_tiled;
   int xcd_order;   // 1 / 0: XCD-contiguous tile order on / off; -1 auto
+  int split_x;     // 1: the x update rides in the direction-update kernel (default)
 };
 
 static int64_t class_count(const int64_t gres[3], int p) {
@@ -874,6 +875,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->mask_cg = env_int("MFS_VISC_MASK_CG", 0);
   h->tiled = env_int("MFS_VISC_TILED", 0);   // measured slower than the direct-load kernel; kept selectable
   h->xcd_order = env_int("MFS_VISC_XCD", -1);
+  h->split_x = env_int("MFS_VISC_SPLIT_X", 1);
   h->xchunk_tiled = std::max(1, env_int("MFS_VISC_XCHUNK", 32));
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
@@ -947,8 +949,13 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
     int e, np = 0;
     if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;   // :589
     h->c.n_part_dq = np;
-    if ((e = core_update_xr(h->c, true, st))) return e;                               // :592-601
-    if ((e = core_update_d(h->c, true, st))) return e;                                // :604-610
+    if (h->split_x) {   // r -= alpha q here, x += alpha d rides in the direction update (8 instead of 9 scalars per DOF)
+      if ((e = core_update_xr(h->c, true, st, 1))) return e;                          // :592-601 (r)
+      if ((e = core_update_d(h->c, true, st, true))) return e;                        // :595-597 (x), :604-610
+    } else {
+      if ((e = core_update_xr(h->c, true, st))) return e;                             // :592-601
+      if ((e = core_update_d(h->c, true, st))) return e;                              // :604-610
+    }
   }
   return MFS_OK;
 }
