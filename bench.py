@@ -246,6 +246,8 @@ def main():
     t0 = time.perf_counter()
     cg.iterate(args.steps)
     t_enq = time.perf_counter() - t0      # host time to enqueue the steps (no sync inside)
+    if transport == "single":
+        eng.finish()                      # the one solution update the fused loop still owes (inside the timed region)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -279,7 +281,10 @@ def main():
         # the dominant kernel of the timed loop is the stencil apply WITH the direction update folded in:
         # SURVEY.md 8(d)'s stencil figure (6N^3+3N^2 scalars: v,4 coefficient arrays in, out) plus the update's
         # r in and d_new out, with d_old taking the place of v = 8N^3+3N^2 scalars per launch
-        alg_bytes = (8 * Nx * Ny * Nz + 3 * Ny * Nz) * esz
+        # ... and, where the loop defers it (grids beyond the Infinity Cache), the previous iteration's x update:
+        # x in, x out (d_old is re-read from cache and not counted) = 10N^3+3N^2
+        form = eng.loop_info()
+        alg_bytes = ((10 if form["deferred_x_update"] else 8) * Nx * Ny * Nz + 3 * Ny * Nz) * esz
         if transport != "single":          # leave the slab loops' state behind: plain single-domain iterations
             eng.begin(0.0)
             eng.iterate(2)
@@ -340,7 +345,9 @@ def main():
                     traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        rf = {"bound": "hbm", "kernel": "k_pcg_apply_march<..., FUSE=true> (stencil apply + d = r + beta d)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        kname = ("k_pcg_apply_march<..., FUSE=true, XDEF=true> (stencil apply + d = r + beta d + x += alpha d_old)"
+                 if form["deferred_x_update"] else "k_pcg_apply_march<..., FUSE=true> (stencil apply + d = r + beta d)")
+        rf = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
               "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5),
               "kernel_ms_raw_events": round(ms_raw, 5), "event_pair_overhead_ms": round(ev_over, 5)}

@@ -115,6 +115,15 @@ int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream);
  * with events): the stencil launch, then the x/r update and the direction update / its bookkeeping */
 int mfs_pcg3d_native_apply(mfs_pcg3d* h, mfs_stream stream);
 int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream);
+/* after mfs_pcg3d_iterate calls of one's own: settle what the fused loop forms still owe -- the deferred x update
+ * (mfs_pcg3d_set_defer_x) and the direction vector parked in the engine's partner buffer -- so that x and d are the
+ * reference's.  mfs_pcg3d_solve does this itself.  Host-synchronous; call once, when no more iterations follow. */
+int mfs_pcg3d_finish(mfs_pcg3d* h, mfs_stream stream);
+/* native fused loop: let `x += alpha d` ride in the NEXT iteration's stencil launch (which re-reads d from cache) so
+ * that the x/r update kernel only streams r and q; same values; the last update is owed until mfs_pcg3d_finish /
+ * the end of mfs_pcg3d_solve.  on < 0 = auto (default; env MFS_DEFER_X): only when the CG vectors exceed the
+ * Infinity Cache.  A caller of mfs_pcg3d_iterate must therefore end with mfs_pcg3d_finish before reading x.   */
+int mfs_pcg3d_set_defer_x(mfs_pcg3d* h, int on);
 /* synchronises `stream`, then reports the device-resident solver state. host call. */
 int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);
@@ -167,6 +176,9 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
  * coefficient arrays only for z-vectors that are neither all-zero rows nor regular
  * interior rows (class byte per vector built by mfs_pcg3d_setup); results are bit-identical */
 int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
+/* form of the native loop for the engine as bound: bit 0 = direction update fused into the stencil launch,
+ * bit 1 = x update deferred into it too, bit 2 = Jacobi loop */
+int mfs_pcg3d_loop_info(mfs_pcg3d* h);
 /* OPT-IN Jacobi preconditioning of the native loop (default off; env MFS_JACOBI=1): z = r / diag fused into the
  * two vector phases, delta = r.z, convergence test unchanged (r.r < tol^2).  NOT the reference's algorithm -- the
  * reference's CG is unpreconditioned and its residual history cannot be matched with this on.  One GPU only.  */

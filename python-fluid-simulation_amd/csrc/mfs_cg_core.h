@@ -319,6 +319,25 @@ k_d_axpy(T* __restrict__ d, const T* __restrict__ r, int64_t n, const double* __
   });
 }
 
+// x += alpha d with alpha as left in the scalar block (delta / d.q of the last completed iteration): the solution
+// update a loop with the deferred x update still owes when it stops (converged or not)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_x_axpy(T* __restrict__ x, const T* __restrict__ d, int64_t n, const double* __restrict__ scal) {
+  const double alpha = scal[S_ALPHA];
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      vec_t<T, VEC> xv = vload<T, VEC>(x + i);
+      const vec_t<T, VEC> dv = vload<T, VEC>(d + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
+      vstore<T, VEC>(x + i, xv);
+    } else {
+      x[i] = (T)((double)x[i] + alpha * (double)d[i]);
+    }
+  });
+}
+
 // The bookkeeping half of k_update_d on its own (one block): r.r from the partials, convergence
 // test (:218), history, iteration count, delta ring, beta (:220).  Used when the direction update
 // itself is folded into the next stencil launch (mfs_pcg_apply.h, FUSE).
@@ -471,7 +490,7 @@ static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode 
                                  int64_t off = 0, int64_t cnt = -1, const XrTail* tail = nullptr,
                                  const P2pDev* pd = nullptr) {
   MFS_REQUIRE(c.x, "engine not bound");
-  MFS_REQUIRE(!tail || mode == 0, "an iteration-closing tail needs the combined x/r update");
+  MFS_REQUIRE(!tail || mode != 2, "an iteration-closing tail needs the r update (it produces r.r)");
   XrTail tl = tail ? *tail : XrTail{};
   if (tail) tl.ticket = c.tickets;
   const P2pDev pdv = pd ? *pd : P2pDev{};

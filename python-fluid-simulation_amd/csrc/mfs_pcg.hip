@@ -188,6 +188,7 @@ struct mfs_pcg3d {
   char* ws;
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
+  int defer_x;                 // 1: native fused loop lets x += alpha d ride in the NEXT stencil launch (mfs_pcg3d_finish owes the last one)
   int jacobi;                  // 1: opt-in Jacobi-preconditioned loop (mfs_pcg3d_set_jacobi); NOT the reference's CG
   double* part_rz;             // partial sums of r.z (Jacobi loop)
   void* cz2;                   // asym only: weight of the -z tap (the density operator, DensityCGSolver3D.py:184)
@@ -213,7 +214,7 @@ struct mfs_pcg3d {
 // streams of one tile do not all start on the same HBM channel/bank phase.
 static size_t coef_stride(int64_t n, size_t elt) { return align_up((size_t)n * elt, 4096) + 4096 * 3 + 256; }
 
-struct FuseArgs { const void* r; const void* d_old; void* d_new; };
+struct FuseArgs { const void* r; const void* d_old; void* d_new; void* xdef = nullptr; };   // xdef: deferred x update rides along
 
 template <typename T, int VEC>
 static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int xb2, int xe2, double* partial,
@@ -263,6 +264,16 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
       else      { if (nt) MFS_GO(false, 1, false, false, 1, false); else MFS_GO(false, 0, false, false, 1, false); }
     } else if (asym) {
       if (fz) MFS_GO_NT_CMP(true, 1, true); else MFS_GO_NT_CMP(false, 1, true);
+    } else if (fz && fz->xdef) {
+      // fused direction update + the previous iteration's x update (PD 1 only)
+#define MFS_GO_X(NTV, CMP)                                                                                             \
+      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, false, true>), dim3(grid), dim3(kApplyBlock), \
+                         lds, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)fz->r, (const T*)fz->d_old, \
+                         (T*)fz->d_new, (const double*)(h->c.scal + S_BETA), cz2, (T*)fz->xdef,                          \
+                         (const double*)(h->c.scal + S_ALPHA))
+      if (comp) { if (nt) MFS_GO_X(7, true); else MFS_GO_X(0, true); }
+      else      { if (nt) MFS_GO_X(7, false); else MFS_GO_X(0, false); }
+#undef MFS_GO_X
     } else if (fz) {
       if (pd == 2) MFS_GO_NT_CMP(true, 2, false); else MFS_GO_NT_CMP(true, 1, false);
     } else if (comp || nt == 0 || nt == 7) {
@@ -341,6 +352,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->cls = (unsigned char*)(p + 6 * cs);
   h->part_rz = (double*)(p + 6 * cs + align_up((size_t)h->n, 4096));
   h->jacobi = env_int("MFS_JACOBI", 0);
+  h->defer_x = env_int("MFS_DEFER_X", -1);
   h->fuse = env_int("MFS_FUSE_D", 1);
   h->pd = env_int("MFS_APPLY_PD", 1);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
@@ -458,6 +470,12 @@ int mfs_pcg3d_set_prefetch(mfs_pcg3d* h, int planes) {
 int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
   h->fuse = on != 0;
+  return MFS_OK;
+}
+
+int mfs_pcg3d_set_defer_x(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->defer_x = on < 0 ? -1 : (on != 0);
   return MFS_OK;
 }
 
@@ -591,6 +609,15 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   return mfs_pcg3d_begin_finish(h, stream);
 }
 
+static bool native_fuse_ok(const mfs_pcg3d* h);
+// deferred x update: fused native loop, symmetric operator, prefetch depth 1, x 16-byte aligned
+static bool xdef_ok(const mfs_pcg3d* h) {
+  // auto (< 0): on once the CG vectors no longer fit the Infinity Cache (256^3 fp32: 134.7 -> 130.2 us/iteration,
+  // fp64: 295 -> 276); below that the extra streams cost the march more than the update kernel saves (128^3: +4 %)
+  const bool on = h->defer_x < 0 ? (5.0 * (double)h->n * h->c.elt > 200e6) : (h->defer_x != 0);
+  return on && native_fuse_ok(h) && !h->asym && h->pd < 2 && ((uintptr_t)h->c.x % 16 == 0);
+}
+
 static bool native_fuse_ok(const mfs_pcg3d* h) {
   const bool vec_in = h->vec_ok && ((uintptr_t)h->c.d % 16 == 0) && ((uintptr_t)h->c.q % 16 == 0) &&
                       ((uintptr_t)h->c.r % 16 == 0);
@@ -611,6 +638,7 @@ int mfs_pcg3d_native_apply(mfs_pcg3d* h, mfs_stream stream) {
     if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid))) return e;
   } else {
     FuseArgs fz{h->c.r, d_prev, d_cur};
+    if (xdef_ok(h)) fz.xdef = h->c.x;
     if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e;
   }
   h->c.n_part_dq = grid;
@@ -628,6 +656,12 @@ int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
   }
   const int64_t j = h->c.iter_enq;
   // the last block of the update closes the iteration (convergence test, history, beta): 2 launches per iteration
+  if (xdef_ok(h)) {   // r only: x += alpha d rides in the next stencil launch
+    XrTail tl{1, h->c.hist, kHistCap, nullptr, 0, 0};
+    if ((e = core_update_xr(h->c, true, st, 1, (j & 1) ? h->d2 : h->c.d, 0, -1, &tl, nullptr))) return e;
+    ++h->c.iter_enq;
+    return MFS_OK;
+  }
   return core_update_xr_close(h->c, true, st, (j & 1) ? h->d2 : h->c.d, 1);
 }
 
@@ -656,6 +690,12 @@ int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
 static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t st) {
   if (!native_fuse_ok(h) || iters < 1 || !h->c.d) return MFS_OK;
   void* cur = ((iters - 1) & 1) ? h->d2 : h->c.d;             // holds d_{iters-1}
+  if (xdef_ok(h)) {                                           // owed: x += alpha_{iters-1} d_{iters-1}
+    const int grid = core_vec_grid(h->c, true);
+    if (h->dt == MFS_F32) hipLaunchKernelGGL((k_x_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.x, (const float*)cur, h->n, h->c.scal);
+    else hipLaunchKernelGGL((k_x_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.x, (const double*)cur, h->n, h->c.scal);
+    MFS_LAUNCH_CHECK();
+  }
   if (!converged) {                                           // owed: d_iters = r + beta d_{iters-1}
     const bool vec = ((uintptr_t)cur % 16 == 0) && ((uintptr_t)h->c.r % 16 == 0);
     const int grid = core_vec_grid(h->c, vec);
@@ -676,6 +716,22 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
                    double* beta) {
   MFS_REQUIRE(h, "null handle");
   return core_poll(h->c, (hipStream_t)stream, iters, done, delta, alpha, beta);
+}
+
+// what the native loop will do for the engine as bound: bit 0 fused direction update, bit 1 deferred x update, bit 2 Jacobi
+int mfs_pcg3d_loop_info(mfs_pcg3d* h) {
+  if (!h || !h->c.x) return 0;
+  return (native_fuse_ok(h) ? 1 : 0) | (xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0);
+}
+
+// for callers that drive begin / iterate themselves: settles what the loop forms owe (the deferred x update, the
+// direction vector parked in the engine's partner buffer).  Host-synchronous (it needs the iteration count).
+int mfs_pcg3d_finish(mfs_pcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  int64_t iters = 0;
+  int done = 0;
+  if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  return pcg_home_d(h, iters, done != 0, (hipStream_t)stream);
 }
 
 int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_every, mfs_stream stream,

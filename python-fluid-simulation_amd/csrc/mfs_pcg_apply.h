@@ -269,13 +269,19 @@ struct VSrc {
 // PD = prefetch depth in planes for the operand vector and its halo rows (the long-latency streams):
 // their loads for plane x+1+PD are issued at step x and consumed PD steps later, which keeps PD
 // planes of v per wave in flight -- the march is latency-paced, so bytes in flight are what set its speed.
-template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD, bool ASYM = false>
+// XDEF (with FUSE): the PREVIOUS iteration's solution update x += alpha d_old rides in this launch too -- each
+// vector is updated by the step that owns it, d_old re-read from cache -- so that the x/r update kernel only
+// touches r and q.  The march is latency-paced, extra streams are nearly free for it; same values as k_update_xr's.
+template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD, bool ASYM = false, bool XDEF = false>
 __global__ void __launch_bounds__(kApplyBlock, MFS_MARCH_MIN_WAVES)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
                   const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
                   const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
                   const double* __restrict__ done_flag, const T* __restrict__ fr, const T* __restrict__ fd_old,
-                  T* __restrict__ fd_new, const double* __restrict__ beta_ptr, const T* __restrict__ cz2) {
+                  T* __restrict__ fd_new, const double* __restrict__ beta_ptr, const T* __restrict__ cz2,
+                  T* __restrict__ xdef = nullptr, const double* __restrict__ alpha_ptr = nullptr) {
+  static_assert(!XDEF || FUSE, "the deferred x update rides on the fused direction update");
+  const double alpha_x = XDEF ? *alpha_ptr : 0.0;
   static_assert(!FUSE || LDS, "the fused direction update is implemented on the LDS march");
   if (done_flag && *done_flag != 0.0) return;
   const VSrc<T, VEC, FUSE> src{v, fr, fd_old, FUSE ? *beta_ptr : 0.0};
@@ -377,6 +383,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const int64_t nn = more ? nb : base;                  // plane x+1 (or x again on the last step)
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
       const RawVec<T, VEC> qn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + m);   // operand vector, plane x+1+PD
+      vec_t<T, VEC> xo = {}, dxo = {};                      // XDEF: this step's own x vector and d_old (cache hit)
+      if (XDEF) { xo = vload_nt<T, VEC>(xdef + base); dxo = vload<T, VEC>(fd_old + base); }
       // plane x+1's coefficients (class known since the previous step); class of plane x+2
       CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT, false, ASYM>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls, cz2);
       cn.cxm = cc.cxp;                                      // cx[x+1] was this step's upper-face weight
@@ -405,6 +413,11 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       stencil_vec<T, VEC>(out + base, vc, vp, vm, vyp, vym, cc.dg, cc.cxp, cc.cxm, cc.cyp, cc.cym, cc.czm, zl, zr, czr,
                           first, last, active, acc, cc.czm2);
       if (FUSE && active) vstore<T, VEC>(fd_new + base, vc);   // d_new of this vector (its z-boundary cells are 0 + beta*0)
+      if (XDEF && active) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xo[j] = (T)((double)xo[j] + alpha_x * (double)dxo[j]);
+        vstore_nt<T, VEC>(xdef + base, xo);
+      }
       // ---- rotate; publish plane x+1 to the other LDS buffer
       if (more) {
         if (LDS) {

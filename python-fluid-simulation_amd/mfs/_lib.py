@@ -71,7 +71,10 @@ SIGNATURES = {
     "mfs_pcg3d_begin_finish": (_i, [_p, _p]),
     "mfs_pcg3d_scalars": (_p, [_p]),
     "mfs_pcg3d_tune": (_i, [_p, _i, _i, _i, _i]),
+    "mfs_pcg3d_loop_info": (_i, [_p]),
     "mfs_pcg3d_set_jacobi": (_i, [_p, _i]),
+    "mfs_pcg3d_set_defer_x": (_i, [_p, _i]),
+    "mfs_pcg3d_finish": (_i, [_p, _p]),
     "mfs_pcg3d_set_compress": (_i, [_p, _i]),
     "mfs_pcg3d_set_fuse": (_i, [_p, _i]),
     "mfs_pcg3d_set_prefetch": (_i, [_p, _i]),

@@ -52,6 +52,17 @@ class PcgEngine:
     def set_fuse(self, on):
         _lib.check(self.lib.mfs_pcg3d_set_fuse(self.h, int(bool(on))), "mfs_pcg3d_set_fuse")
 
+    def loop_info(self):
+        b = int(self.lib.mfs_pcg3d_loop_info(self.h))
+        return dict(fused_direction_update=bool(b & 1), deferred_x_update=bool(b & 2), jacobi=bool(b & 4))
+
+    def set_defer_x(self, on):
+        _lib.check(self.lib.mfs_pcg3d_set_defer_x(self.h, -1 if on is None else int(bool(on))), "mfs_pcg3d_set_defer_x")
+
+    def finish(self):
+        """after iterate() calls of one's own: settle the deferred x update / parked direction vector"""
+        _lib.check(self.lib.mfs_pcg3d_finish(self.h, T.stream()), "mfs_pcg3d_finish")
+
     def set_jacobi(self, on):
         """opt-in Jacobi preconditioning (NOT the reference's CG: fewer iterations, different residual history)"""
         _lib.check(self.lib.mfs_pcg3d_set_jacobi(self.h, int(bool(on))), "mfs_pcg3d_set_jacobi")
@@ -102,6 +113,8 @@ class PcgEngine:
         _lib.check(self.lib.mfs_pcg3d_begin(self.h, float(tol), T.stream()), "mfs_pcg3d_begin")
 
     def iterate(self, n):
+        """enqueue n iterations.  On large grids the loop defers the last `x += alpha d` (and may park `d` in the
+        engine's partner buffer): call finish() before reading x or d.  solve() does that itself."""
         _lib.check(self.lib.mfs_pcg3d_iterate(self.h, int(n), T.stream()), "mfs_pcg3d_iterate")
 
     def native_apply(self):
