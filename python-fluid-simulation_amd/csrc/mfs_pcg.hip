@@ -188,6 +188,7 @@ struct mfs_pcg3d {
   char* ws;
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
+  bool x_owed;                 // the native loop has deferred an x update that pcg_home_d still has to apply
   int defer_x;                 // 1: native fused loop lets x += alpha d ride in the NEXT stencil launch (mfs_pcg3d_finish owes the last one)
   int jacobi;                  // 1: opt-in Jacobi-preconditioned loop (mfs_pcg3d_set_jacobi); NOT the reference's CG
   double* part_rz;             // partial sums of r.z (Jacobi loop)
@@ -353,6 +354,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->part_rz = (double*)(p + 6 * cs + align_up((size_t)h->n, 4096));
   h->jacobi = env_int("MFS_JACOBI", 0);
   h->defer_x = env_int("MFS_DEFER_X", -1);
+  h->x_owed = false;
   h->fuse = env_int("MFS_FUSE_D", 1);
   h->pd = env_int("MFS_APPLY_PD", 1);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
@@ -547,6 +549,7 @@ int mfs_pcg3d_phase_update_d(mfs_pcg3d* h, mfs_stream stream) {
 
 int mfs_pcg3d_begin_local(mfs_pcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  h->x_owed = false;
   hipStream_t st = (hipStream_t)stream;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;
@@ -657,6 +660,7 @@ int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
   const int64_t j = h->c.iter_enq;
   // the last block of the update closes the iteration (convergence test, history, beta): 2 launches per iteration
   if (xdef_ok(h)) {   // r only: x += alpha d rides in the next stencil launch
+    h->x_owed = true;
     XrTail tl{1, h->c.hist, kHistCap, nullptr, 0, 0};
     if ((e = core_update_xr(h->c, true, st, 1, (j & 1) ? h->d2 : h->c.d, 0, -1, &tl, nullptr))) return e;
     ++h->c.iter_enq;
@@ -690,7 +694,8 @@ int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
 static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t st) {
   if (!native_fuse_ok(h) || iters < 1 || !h->c.d) return MFS_OK;
   void* cur = ((iters - 1) & 1) ? h->d2 : h->c.d;             // holds d_{iters-1}
-  if (xdef_ok(h)) {                                           // owed: x += alpha_{iters-1} d_{iters-1}
+  if (h->x_owed) {                                            // owed: x += alpha_{iters-1} d_{iters-1}
+    h->x_owed = false;
     const int grid = core_vec_grid(h->c, true);
     if (h->dt == MFS_F32) hipLaunchKernelGGL((k_x_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.x, (const float*)cur, h->n, h->c.scal);
     else hipLaunchKernelGGL((k_x_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.x, (const double*)cur, h->n, h->c.scal);
@@ -873,6 +878,7 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   MFS_REQUIRE(slab_ok(h), "slab loop needs an attached window, the vector path (Nz % 4 (fp32) / 2 (fp64) == 0, 16-byte aligned CG vectors) and stencil variant 2");
   hipStream_t st = (hipStream_t)stream;
+  h->x_owed = false;
   ++h->p2p->epoch;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;
