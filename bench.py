@@ -246,7 +246,7 @@ def main():
     t0 = time.perf_counter()
     cg.iterate(args.steps)
     t_enq = time.perf_counter() - t0      # host time to enqueue the steps (no sync inside)
-    if transport == "single":
+    if transport in ("single", "p2p"):
         eng.finish()                      # the one solution update the fused loop still owes (inside the timed region)
     sync()
     dt = time.perf_counter() - t0

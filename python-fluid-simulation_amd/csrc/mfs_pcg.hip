@@ -188,7 +188,8 @@ struct mfs_pcg3d {
   char* ws;
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
-  bool x_owed;                 // the native loop has deferred an x update that pcg_home_d still has to apply
+  bool x_owed;                 // the loop has deferred an x update that pcg_home_d still has to apply
+  bool slab_loop;              // the running solve is the slab loop (x lives on the owned planes [1, Nx-1) only)
   int defer_x;                 // 1: native fused loop lets x += alpha d ride in the NEXT stencil launch (mfs_pcg3d_finish owes the last one)
   int jacobi;                  // 1: opt-in Jacobi-preconditioned loop (mfs_pcg3d_set_jacobi); NOT the reference's CG
   double* part_rz;             // partial sums of r.z (Jacobi loop)
@@ -355,6 +356,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->jacobi = env_int("MFS_JACOBI", 0);
   h->defer_x = env_int("MFS_DEFER_X", -1);
   h->x_owed = false;
+  h->slab_loop = false;
   h->fuse = env_int("MFS_FUSE_D", 1);
   h->pd = env_int("MFS_APPLY_PD", 1);
   h->compress = env_int("MFS_APPLY_COMPRESS", 1);
@@ -550,6 +552,7 @@ int mfs_pcg3d_phase_update_d(mfs_pcg3d* h, mfs_stream stream) {
 int mfs_pcg3d_begin_local(mfs_pcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   h->x_owed = false;
+  h->slab_loop = false;
   hipStream_t st = (hipStream_t)stream;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;
@@ -697,8 +700,10 @@ static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t s
   if (h->x_owed) {                                            // owed: x += alpha_{iters-1} d_{iters-1}
     h->x_owed = false;
     const int grid = core_vec_grid(h->c, true);
-    if (h->dt == MFS_F32) hipLaunchKernelGGL((k_x_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.x, (const float*)cur, h->n, h->c.scal);
-    else hipLaunchKernelGGL((k_x_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.x, (const double*)cur, h->n, h->c.scal);
+    const int64_t plane = (int64_t)h->Ny * h->Nz;
+    const int64_t off = h->slab_loop ? plane : 0, cnt = h->slab_loop ? plane * (h->Nx - 2) : h->n;   // ghost planes are not ours
+    if (h->dt == MFS_F32) hipLaunchKernelGGL((k_x_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.x + off, (const float*)cur + off, cnt, h->c.scal);
+    else hipLaunchKernelGGL((k_x_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.x + off, (const double*)cur + off, cnt, h->c.scal);
     MFS_LAUNCH_CHECK();
   }
   if (!converged) {                                           // owed: d_iters = r + beta d_{iters-1}
@@ -789,6 +794,8 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
   const int64_t plane_elems = (int64_t)h->Ny * h->Nz;
   const unsigned halo_tag = 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)((j + 1) & 0xfffff);
   int e_;
+  // deferred x update (as in the native loop): x += alpha_{j-1} d_{j-1} rides in this iteration's edge / interior launches
+  const bool xdef = xdef_ok(h) && L - 2 > 2;
   // 1. edge planes of d_j: local + into the neighbours' windows -- on the second stream, behind everything
   //    the main stream has done so far (beta, r of the previous iteration)
   const bool aux = h->use_aux && h->aux && e.np > 0 && L - 2 > 2;
@@ -801,10 +808,10 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(4 * h->cus, (plane_elems / VEC + kBlock - 1) / kBlock));
     if (j == 0)
       hipLaunchKernelGGL((k_slab_edge_d<T, VEC, true>), dim3(grid), dim3(kBlock), 0, se, (const T*)nullptr, (const T*)d_cur,
-                         (T*)nullptr, plane_elems, e, h->c.scal, p->dev, par, halo_tag);
+                         (T*)nullptr, plane_elems, e, h->c.scal, p->dev, par, halo_tag, (T*)nullptr);
     else
       hipLaunchKernelGGL((k_slab_edge_d<T, VEC, false>), dim3(grid), dim3(kBlock), 0, se, (const T*)h->c.r, (const T*)d_prev,
-                         d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag);
+                         d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag, xdef ? (T*)h->c.x : (T*)nullptr);
     MFS_LAUNCH_CHECK();
   }
   if (aux) MFS_HIP_TRY(hipEventRecord(h->ev_aux, h->aux));
@@ -816,6 +823,7 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
       if ((e_ = apply_dispatch(h, d_cur, h->c.q, 2, L - 2, h->c.part_dq, 1, st, &grid))) return e_;
     } else {
       FuseArgs fz{h->c.r, d_prev, d_cur};
+      if (xdef) fz.xdef = h->c.x;
       if ((e_ = apply_dispatch(h, d_cur, h->c.q, 2, L - 2, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e_;
     }
     n_part = grid;
@@ -833,7 +841,14 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     n_part += grid;
   }
   h->c.n_part_dq = n_part;
-  // 4. x, r update; its last block: r.r over all ranks + bookkeeping (closes the iteration)
+  // 4. x, r update (r only when the x update is deferred); its last block: r.r over all ranks + bookkeeping
+  if (xdef) {
+    h->x_owed = true;
+    XrTail tl{2, h->c.hist, kHistCap, nullptr, (int)((2 * j + 2) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 2)};
+    if ((e_ = core_update_xr(h->c, false, st, 1, d_cur, plane_elems, plane_elems * (L - 2), &tl, &p->dev))) return e_;
+    ++h->c.iter_enq;
+    return MFS_OK;
+  }
   return core_update_xr_close(h->c, false, st, d_cur, 2, plane_elems, plane_elems * (L - 2), &p->dev,
                               (int)((2 * j + 2) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 2));
 }
@@ -879,6 +894,7 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(slab_ok(h), "slab loop needs an attached window, the vector path (Nz % 4 (fp32) / 2 (fp64) == 0, 16-byte aligned CG vectors) and stencil variant 2");
   hipStream_t st = (hipStream_t)stream;
   h->x_owed = false;
+  h->slab_loop = true;
   ++h->p2p->epoch;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;

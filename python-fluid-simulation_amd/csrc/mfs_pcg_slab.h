@@ -46,12 +46,15 @@ static inline SlabEdge slab_edges(int L, int rank, int world) {
 
 // d_new = r + beta d_old on the edge planes (exactly k_update_d's expression); FIRST: iteration 0,
 // the direction vector is d_old itself and nothing is written locally.
+// xdef != null (never with FIRST): the deferred solution update x += alpha d_old of the previous iteration on
+// the edge planes too (the interior launch does it for its own planes).
 template <typename T, int VEC, bool FIRST>
 __global__ void __launch_bounds__(kBlock)
 k_slab_edge_d(const T* __restrict__ r, const T* __restrict__ d_old, T* __restrict__ d_new, int64_t plane_elems,
-              SlabEdge e, const double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
+              SlabEdge e, const double* __restrict__ scal, P2pDev pd, int par, unsigned tag, T* __restrict__ xdef) {
   if (scal[S_DONE] != 0.0) return;
   const double beta = FIRST ? 0.0 : scal[S_BETA];
+  const double alpha_x = (!FIRST && xdef) ? scal[S_ALPHA] : 0.0;
   const int64_t nv = plane_elems / VEC, stride = (int64_t)gridDim.x * blockDim.x;
   for (int k = 0; k < e.np; ++k) {
     const int64_t p0 = (int64_t)e.plane[k] * plane_elems;
@@ -60,6 +63,12 @@ k_slab_edge_d(const T* __restrict__ r, const T* __restrict__ d_old, T* __restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
       vec_t<T, VEC> dv = vload<T, VEC>(d_old + p0 + i * VEC);
       if (!FIRST) {
+        if (xdef) {
+          vec_t<T, VEC> xv = vload<T, VEC>(xdef + p0 + i * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) xv[j] = (T)((double)xv[j] + alpha_x * (double)dv[j]);
+          vstore<T, VEC>(xdef + p0 + i * VEC, xv);
+        }
         const vec_t<T, VEC> rv = vload<T, VEC>(r + p0 + i * VEC);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) dv[j] = (T)((double)rv[j] + beta * (double)dv[j]);

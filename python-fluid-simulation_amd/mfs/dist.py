@@ -154,6 +154,12 @@ class SlabCG:
                 self._allreduce(_lib.S_RR)
             ops.phase_update_d()
 
+    def finish(self):
+        """for callers of begin / iterate: settle what the device loop still owes (the deferred solution update,
+        the direction vector's home buffer).  solve() does this itself."""
+        if getattr(self, "_p2p_active", False) or not self.multi:
+            self.ops.finish()
+
     def solve(self, tol, max_iter, check_every=32):
         """begin + iterate until the device-resident `done` flag or max_iter; returns (converged, iterations).
         COLLECTIVE.  The scalars every rank tests are bit-identical, so all ranks leave the loop together."""

@@ -112,6 +112,7 @@ def main():
                 cg.iterate(8)
                 n += 8
                 st = eng.poll()
+            cg.finish()                  # callers of begin / iterate settle the deferred x update themselves
         torch.cuda.synchronize()
         xc = x.cpu()                     # gloo moves host tensors; on the GPUs (bench.py) RCCL moves device planes
         cg.exchange(xc)
