@@ -245,6 +245,13 @@ size_t mfs_visc_extrapolate3d_workspace_bytes(const int64_t gres[3], int v_dt);
 int mfs_visc_extrapolate3d(const int64_t gres[3], int num_iter, void* vx, void* vy, void* vz, int v_dt,
                            const void* sphi, int sphi_dt, void* workspace, size_t workspace_bytes,
                            mfs_stream stream);
+/* the two pieces of extrapolate, for callers that act between sweeps (slab decomposition: the ghost planes of
+ * values and validity travel after every sweep).  comp = 0/1/2 (vx/vy/vz); valid = one byte per face:
+ * `valid = sphi(face) >= 0` (:479-481), then one Jacobi sweep old -> new (:8-39, the loop body of :483-502) */
+int mfs_visc_valid3d(const int64_t gres[3], int comp, const void* sphi, int sphi_dt, unsigned char* valid,
+                     mfs_stream stream);
+int mfs_visc_extrapolate_sweep3d(const int64_t gres[3], int comp, const void* v_in, void* v_out, int v_dt,
+                                 const unsigned char* valid_in, unsigned char* valid_out, mfs_stream stream);
 /* replaces initialize_solver -- solver/ViscosityCGSolver3D.py:41-246,504-513.
  * `vol` is the doubled-grid fluid volume already divided by cell_vol/8 (self.vol, :568) */
 int mfs_visc_rhs3d(const int64_t gres[3], double scale, double mu,
@@ -288,6 +295,19 @@ int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters_host, int* do
 int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every,
                     mfs_stream stream, int64_t* iters_host);
 int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream);
+/* Slab decomposition along x (the build's extension; host driver mfs/dist.py:SlabVCG): one
+ * iteration = halo exchange of d's edge planes (3 components), phase_apply, phase_reduce(0), all-reduce of
+ * scalars[MFS_PCG_S_DQ], phase_update_xr, phase_reduce(1), all-reduce of scalars[MFS_PCG_S_RR], phase_update_d
+ * -- the same phases and scalar block (device pointer: mfs_vcg3d_scalars) as mfs_pcg3d_phase_*.
+ * set_slab(skip_top_x = 1) on every rank but the last: its last u plane is the right neighbour's.       */
+int mfs_vcg3d_set_slab(mfs_vcg3d* h, int skip_top_x);
+void* mfs_vcg3d_scalars(mfs_vcg3d* h);
+int mfs_vcg3d_begin_local(mfs_vcg3d* h, double tol, mfs_stream stream);
+int mfs_vcg3d_begin_finish(mfs_vcg3d* h, mfs_stream stream);
+int mfs_vcg3d_phase_apply(mfs_vcg3d* h, mfs_stream stream);
+int mfs_vcg3d_phase_reduce(mfs_vcg3d* h, int which, mfs_stream stream);
+int mfs_vcg3d_phase_update_xr(mfs_vcg3d* h, mfs_stream stream);
+int mfs_vcg3d_phase_update_d(mfs_vcg3d* h, mfs_stream stream);
 
 /* ------------------------------------------------------------------------- */
 /* Density solver, 3D -- reference solver/DensityCGSolver3D.py */

@@ -585,6 +585,7 @@ struct mfs_vcg3d {
   int xchunk_tiled;
   int xcd_order;   // 1 / 0: XCD-contiguous tile order on / off; -1 auto
   int split_x;     // 1: the x update rides in the direction-update kernel (default)
+  int skip_top_x;  // slab decomposition: the u row at x = Nx-1 belongs to the right neighbour (a ghost here)
 };
 
 static int64_t class_count(const int64_t gres[3], int p) {
@@ -675,12 +676,12 @@ static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial,
   };
   if (Nx >= 3 && Ny >= 3 && Nz >= 3) {
     const Box3 b0 = slab(0), b1 = slab(1), b2 = slab(2);
-    const int g0 = sgrid(b0), g1 = sgrid(b1), g2 = sgrid(b2);
+    const int g0 = h->skip_top_x ? 0 : sgrid(b0), g1 = sgrid(b1), g2 = sgrid(b2);
     hipLaunchKernelGGL((k_vcg_apply_slabs<T, MASK>), dim3(g0 + g1 + g2), dim3(256), 0, st, h->cp, h->k1, h->k2, vv,
                        ob + h->off[0], ob + h->off[1], ob + h->off[2], b0, b1, b2, g0, g1, partial + used, done);
     used += g0 + g1 + g2;
   } else {   // degenerate grids: whichever slabs exist, one launch each
-    if (Nx >= 2 && Ny >= 3 && Nz >= 3) {
+    if (Nx >= 2 && Ny >= 3 && Nz >= 3 && !h->skip_top_x) {
       const Box3 b = slab(0); const int g = sgrid(b);
       hipLaunchKernelGGL((k_vcg_apply_row<T, 0, MASK>), dim3(g), dim3(256), 0, st, h->cp, h->k1, h->k2, vv, ob + h->off[0], b, partial + used, done);
       used += g;
@@ -761,6 +762,38 @@ static int extrapolate_impl(const int64_t gres[3], int num_iter, void* vx, void*
     MFS_LAUNCH_CHECK();
     if (cur != v[c]) MFS_HIP_TRY(hipMemcpyAsync(v[c], cur, (size_t)n * dtype_size(v_dt), hipMemcpyDeviceToDevice, st));
   }
+  return MFS_OK;
+}
+
+// the two pieces of `extrapolate` for callers that must act between sweeps (slab decomposition: ghost planes of
+// the values AND of the validity travel after every sweep)
+int mfs_visc_valid3d(const int64_t gres[3], int comp, const void* sphi, int sphi_dt, unsigned char* valid,
+                     mfs_stream stream) {
+  if (int e = check_gres(gres)) return e;
+  MFS_REQUIRE(sphi && valid, "null array");
+  MFS_REQUIRE(dtype_ok(sphi_dt), "dtype");
+  MFS_REQUIRE(comp >= 0 && comp < 3, "comp must be 0, 1 or 2");
+  G3 g = make_g(gres);
+  const int grid = cdiv(g.nface(comp), 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (comp == 0) hipLaunchKernelGGL((k_visc_valid<0>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, valid);
+  if (comp == 1) hipLaunchKernelGGL((k_visc_valid<1>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, valid);
+  if (comp == 2) hipLaunchKernelGGL((k_visc_valid<2>), dim3(grid), dim3(256), 0, st, g, sphi, sphi_dt, valid);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+int mfs_visc_extrapolate_sweep3d(const int64_t gres[3], int comp, const void* v_in, void* v_out, int v_dt,
+                                 const unsigned char* valid_in, unsigned char* valid_out, mfs_stream stream) {
+  if (int e = check_gres(gres)) return e;
+  MFS_REQUIRE(v_in && v_out && valid_in && valid_out, "null array");
+  MFS_REQUIRE(v_in != v_out && valid_in != valid_out, "a sweep reads the old arrays and writes new ones");
+  MFS_REQUIRE(dtype_ok(v_dt), "dtype");
+  MFS_REQUIRE(comp >= 0 && comp < 3, "comp must be 0, 1 or 2");
+  G3 g = make_g(gres);
+  hipLaunchKernelGGL(k_visc_extrap_sweep, dim3(cdiv(g.nface(comp), 256)), dim3(256), 0, (hipStream_t)stream,
+                     g.sh(comp, 0), g.sh(comp, 1), g.sh(comp, 2), v_in, v_out, v_dt, valid_in, valid_out);
+  MFS_LAUNCH_CHECK();
   return MFS_OK;
 }
 
@@ -876,6 +909,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->tiled = env_int("MFS_VISC_TILED", 0);   // measured slower than the direct-load kernel; kept selectable
   h->xcd_order = env_int("MFS_VISC_XCD", -1);
   h->split_x = env_int("MFS_VISC_SPLIT_X", 1);
+  h->skip_top_x = 0;
   h->xchunk_tiled = std::max(1, env_int("MFS_VISC_XCHUNK", 32));
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
@@ -940,6 +974,56 @@ int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;   // :575
   if (int e = core_begin_post(h->c, st)) return e;                // :577-585
   return core_begin_finish(h->c, st);
+}
+
+// ---- slab decomposition along x (mfs/dist.py:SlabVCG): the phases of one iteration, so that the caller can put the
+// halo exchange of d and the two scalar all-reduces (on the engine's scalar block) between them.
+// skip_top_x: this rank's last u plane is a ghost of the right neighbour's first owned one -- not computed here,
+// so q (and with b = 0 there, r) stay exactly 0 on it and the local dot products count owned faces only.
+int mfs_vcg3d_set_slab(mfs_vcg3d* h, int skip_top_x) {
+  MFS_REQUIRE(h, "null handle");
+  h->skip_top_x = skip_top_x ? 1 : 0;
+  return MFS_OK;
+}
+
+void* mfs_vcg3d_scalars(mfs_vcg3d* h) { return h ? h->c.scal : nullptr; }
+
+int mfs_vcg3d_begin_local(mfs_vcg3d* h, double tol, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = core_begin_pre(h->c, tol, false, st)) return e;
+  int np = 0;
+  if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
+  return core_begin_post(h->c, st);          // local r.r in the scalar block: all-reduce it, then begin_finish
+}
+
+int mfs_vcg3d_begin_finish(mfs_vcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  return core_begin_finish(h->c, (hipStream_t)stream);
+}
+
+int mfs_vcg3d_phase_apply(mfs_vcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.d && h->is_setup, "engine not bound / set up");
+  int np = 0;
+  if (int e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, (hipStream_t)stream, &np)) return e;
+  h->c.n_part_dq = np;
+  return MFS_OK;
+}
+
+int mfs_vcg3d_phase_reduce(mfs_vcg3d* h, int which, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  MFS_REQUIRE(which == 0 || which == 1, "which must be 0 (d.q) or 1 (r.r)");
+  return core_reduce(h->c, which, 1, (hipStream_t)stream);
+}
+
+int mfs_vcg3d_phase_update_xr(mfs_vcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  return core_update_xr(h->c, false, (hipStream_t)stream);
+}
+
+int mfs_vcg3d_phase_update_d(mfs_vcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  return core_update_d(h->c, false, (hipStream_t)stream);
 }
 
 int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {

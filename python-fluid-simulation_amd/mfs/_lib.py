@@ -107,6 +107,16 @@ SIGNATURES = {
     "mfs_vcg3d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
     "mfs_vcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
     "mfs_vcg3d_history": (_i64, [_p, _pd, _i64, _p]),
+    "mfs_vcg3d_set_slab": (_i, [_p, _i]),
+    "mfs_vcg3d_scalars": (_p, [_p]),
+    "mfs_vcg3d_begin_local": (_i, [_p, _d, _p]),
+    "mfs_vcg3d_begin_finish": (_i, [_p, _p]),
+    "mfs_vcg3d_phase_apply": (_i, [_p, _p]),
+    "mfs_vcg3d_phase_reduce": (_i, [_p, _i, _p]),
+    "mfs_vcg3d_phase_update_xr": (_i, [_p, _p]),
+    "mfs_vcg3d_phase_update_d": (_i, [_p, _p]),
+    "mfs_visc_valid3d": (_i, [_pi64, _i, _p, _i, _p, _p]),
+    "mfs_visc_extrapolate_sweep3d": (_i, [_pi64, _i, _p, _p, _i, _p, _p, _p]),
     "mfs_grid_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "mfs_grid_boundary_condition3d": (_i, [_pi64, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _d, _p, _p, _p, _i, _p]),
     "mfs_pcg3d_setup_density": (_i, [_p, _p, _i, _p, _p, _p, _i, _p]),

@@ -207,3 +207,90 @@ class SlabCG:
                 t[0].copy_(src[0])
             if p.right is not None:
                 t[L - 1].copy_(src[L - 1])
+
+
+def exchange_edge_planes(dist, group, part, fields, L):
+    """Halo exchange of several local fields at once: for each tensor (first axis = local plane index, planes 0 and
+    L-1 ghost / boundary) plane 1 goes to the left neighbour's plane L'-1 and plane L-2 to the right neighbour's
+    plane 0.  One batch of sends / receives for all fields.  RCCL moves device planes; any other backend (gloo
+    in the tests) gets host copies."""
+    if dist is None or part.world == 1:
+        return
+    staged = any(getattr(t, "is_cuda", False) for t in fields) and dist.get_backend(group) != "nccl"
+    srcs = [({k: t[k].cpu() for k in (0, 1, L - 2, L - 1)} if staged else t) for t in fields]
+    ops = []
+    for src in srcs:
+        if part.left is not None:
+            ops.append(dist.P2POp(dist.isend, src[1], part.left, group))
+            ops.append(dist.P2POp(dist.irecv, src[0], part.left, group))
+        if part.right is not None:
+            ops.append(dist.P2POp(dist.isend, src[L - 2], part.right, group))
+            ops.append(dist.P2POp(dist.irecv, src[L - 1], part.right, group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    if staged:
+        for t, src in zip(fields, srcs):
+            if part.left is not None:
+                t[0].copy_(src[0])
+            if part.right is not None:
+                t[L - 1].copy_(src[L - 1])
+
+
+class SlabVCG:
+    """The viscosity CG (three staggered components) over one x-slab: the same decomposition as SlabCG.
+
+    Rank p holds cell planes [a_p - 1, a_{p+1} + 1) of the global grid (L planes), hence u (x-face) planes
+    [a_p - 1, a_{p+1} + 1] (L + 1 of them) and v / w planes as cells.  In local indices, for all three
+    components: plane 0 = ghost (left neighbour's plane L'-2) or global array boundary, planes [1, L-1) owned,
+    plane L-1 = ghost (right neighbour's plane 1) -- except on the last rank, whose u plane L-1 is the real
+    global face Nx-1 and is computed there (`set_slab(skip_top_x)` is off on that rank only); u plane L is never
+    read.  The single-domain kernels run unmodified on the local arrays (they skip array-boundary faces exactly
+    where the ghosts are); with b = 0 on the ghost planes, q and r stay 0 there, so the local dot products are
+    the owned sums.  Per iteration: one halo exchange of d (3 components, one batch), two scalar all-reduces.
+    `ops`: mfs.vcg.VcgEngine (or a stand-in with the same phase interface); `d_views`: the three component
+    views of the bound direction vector."""
+
+    def __init__(self, ops, part, d_views, dist=None, group=None):
+        self.ops, self.part, self.dist, self.group = ops, part, dist, group
+        self.d_views = list(d_views)
+        self.L = int(self.d_views[1].shape[0])
+        if self.L != part.local_planes or int(self.d_views[0].shape[0]) != self.L + 1:
+            raise ValueError("d views do not match the partition's local plane count")
+        self.multi = dist is not None and part.world > 1
+        ops.set_slab(part.right is not None)
+
+    def _allreduce(self, slot):
+        if self.multi:
+            self.dist.all_reduce(self.ops.scalars[slot:slot + 1], group=self.group)
+
+    def exchange(self, fields):
+        exchange_edge_planes(self.dist if self.multi else None, self.group, self.part, list(fields), self.L)
+
+    def begin(self, tol):
+        self.ops.begin_local(tol)              # q = A x on the local slab (x's ghosts are the caller's), d = r = b - q
+        self._allreduce(_lib.S_RR)
+        self.ops.begin_finish()
+
+    def iterate(self, n):
+        ops = self.ops
+        for _ in range(int(n)):
+            self.exchange(self.d_views)
+            ops.phase_apply()
+            ops.phase_reduce(0)
+            self._allreduce(_lib.S_DQ)
+            ops.phase_update_xr()
+            ops.phase_reduce(1)
+            self._allreduce(_lib.S_RR)
+            ops.phase_update_d()
+
+    def solve(self, tol, max_iter, check_every=32):
+        """COLLECTIVE; returns (converged, iterations).  Every rank tests the same all-reduced scalars."""
+        self.begin(tol)
+        st = self.ops.poll()
+        enq = 0
+        while not st["done"] and enq < max_iter:
+            n = min(int(check_every), int(max_iter) - enq)
+            self.iterate(n)
+            enq += n
+            st = self.ops.poll()
+        return bool(st["done"]), int(st["iterations"])

@@ -30,6 +30,9 @@ class VcgEngine:
             _lib.check(self.lib.mfs_vcg3d_create(C.byref(h), g, self.code, T.ptr(self.workspace), nbytes, T.stream()),
                        "mfs_vcg3d_create")
         self.h = h
+        # the engine's scalar block is the first bytes of the workspace (all-reduced in place by mfs.dist.SlabVCG)
+        self.scalars = self.workspace[: _lib.NSCALARS * 8].view(torch.float64)
+        assert self.scalars.data_ptr() == self.lib.mfs_vcg3d_scalars(self.h)
         self._bound = None
 
     def __del__(self):
@@ -76,6 +79,28 @@ class VcgEngine:
 
     def iterate(self, n):
         _lib.check(self.lib.mfs_vcg3d_iterate(self.h, int(n), T.stream()), "mfs_vcg3d_iterate")
+
+    # ---- slab decomposition (mfs/dist.py:SlabVCG): the phases of one iteration
+    def set_slab(self, skip_top_x):
+        _lib.check(self.lib.mfs_vcg3d_set_slab(self.h, int(bool(skip_top_x))), "mfs_vcg3d_set_slab")
+
+    def begin_local(self, tol):
+        _lib.check(self.lib.mfs_vcg3d_begin_local(self.h, float(tol), T.stream()), "mfs_vcg3d_begin_local")
+
+    def begin_finish(self):
+        _lib.check(self.lib.mfs_vcg3d_begin_finish(self.h, T.stream()), "mfs_vcg3d_begin_finish")
+
+    def phase_apply(self):
+        _lib.check(self.lib.mfs_vcg3d_phase_apply(self.h, T.stream()), "mfs_vcg3d_phase_apply")
+
+    def phase_reduce(self, which):
+        _lib.check(self.lib.mfs_vcg3d_phase_reduce(self.h, int(which), T.stream()), "mfs_vcg3d_phase_reduce")
+
+    def phase_update_xr(self):
+        _lib.check(self.lib.mfs_vcg3d_phase_update_xr(self.h, T.stream()), "mfs_vcg3d_phase_update_xr")
+
+    def phase_update_d(self):
+        _lib.check(self.lib.mfs_vcg3d_phase_update_d(self.h, T.stream()), "mfs_vcg3d_phase_update_d")
 
     def poll(self):
         it, done = C.c_int64(), C.c_int()

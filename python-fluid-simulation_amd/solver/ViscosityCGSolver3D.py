@@ -133,3 +133,90 @@ class ViscosityCGSolver3D:
             if not ok:
                 raise ValueError("Failed to converge!")
             apply_viscosity(g, vx, vy, vz, self.x_x, self.x_y, self.x_z, sphi, sv)   # :613
+
+
+def _extrapolate_slab(g, num_iter, comps, sphi, slab):
+    """`extrapolate` on one rank's slab: the reference's Jacobi sweeps (:483-502) read the 6 neighbours' values AND
+    validity of the previous sweep, so both ghost planes of both travel after every sweep."""
+    lib = _lib.load()
+    gi = _lib.i64x(g)
+    for c, v in enumerate(comps):
+        tmp = torch.empty_like(v)
+        va = torch.empty(v.shape, dtype=torch.uint8, device=v.device)
+        vb = torch.empty_like(va)
+        _lib.check(lib.mfs_visc_valid3d(gi, c, T.ptr(sphi), T.code(sphi), T.ptr(va), T.stream()), "mfs_visc_valid3d")
+        cur, oth, mcur, moth = v, tmp, va, vb
+        for _ in range(int(num_iter)):
+            _lib.check(lib.mfs_visc_extrapolate_sweep3d(gi, c, T.ptr(cur), T.ptr(oth), T.code(v), T.ptr(mcur),
+                                                        T.ptr(moth), T.stream()), "mfs_visc_extrapolate_sweep3d")
+            slab.exchange([oth, moth])
+            cur, oth, mcur, moth = oth, cur, moth, mcur
+        if cur is not v:
+            v.copy_(cur)
+
+
+class SlabViscosityCGSolver3D(ViscosityCGSolver3D):
+    """One rank of a multi-GPU `ViscosityCGSolver3D` (extension: the reference is single-GPU).
+
+    The GLOBAL grid `gres` is cut into contiguous x-slabs (`mfs.dist.SlabPartition`, as for the pressure solve);
+    one process per GPU.  Every array handed to `solve` is the rank's LOCAL slab with one ghost / boundary cell
+    plane on each side: with (lo, hi) = self.part.local_range, vx = global planes [lo, hi + 1), vy / vz / lphi =
+    [lo, hi), sphi / sv / lvol = doubled planes [2 lo, 2 hi + 1).  `solve` has the reference's signature and
+    semantics on the global problem: same extrapolation, RHS and CG iterates (up to the summation order of the two
+    dot products across ranks), `ValueError("Failed to converge!")` after prod(global gres) iterations, velocities
+    written in place on the local planes (the ghost planes receive the neighbours' values).  Collective: every
+    rank calls `solve` in step.  Transport: torch.distributed (RCCL on the GPUs): per iteration one batched halo
+    exchange of the direction vector's edge planes and two scalar all-reduces (mfs.dist.SlabVCG)."""
+
+    @staticmethod
+    def local_gres(gres, world, rank):
+        from mfs.dist import SlabPartition
+        g = T.as_gres(gres)
+        return (SlabPartition(g[0], world, rank).local_planes, g[1], g[2])
+
+    def __init__(self, gres, bound_size, dist, group=None, precision=None, device=None, check_every=32):
+        from mfs.dist import SlabPartition, SlabVCG
+        gg = T.as_gres(gres)
+        self.global_gres = gg
+        self.dist, self.group = dist, group
+        self.part = SlabPartition(gg[0], dist.get_world_size(group), dist.get_rank(group))
+        lg = (self.part.local_planes, gg[1], gg[2])
+        super().__init__(lg, bound_size, precision, device, check_every)
+        # cell size, cell volume and the iteration cap are the GLOBAL problem's (reference :535-537, :564)
+        self.cell_size = np.array(T.as_f64_list(bound_size, 3)) / np.array(gg, dtype=np.float64)
+        self.cell_vol = float(np.prod(self.cell_size))
+        self.max_iter = int(np.prod(gg))
+        self._cg = SlabVCG(self._engine, self.part, (self.d_x, self.d_y, self.d_z), dist, group)
+
+    def solve(self, dt, mu, rho, vx, vy, vz, sphi, sv, lphi, lvol, tol=1e-3):
+        g = self._g
+        L = g[0]
+        scale = dt / self.cell_vol / rho
+        lvol = T.dev(lvol, "lvol", T.doubled_shape(g))
+        sphi = T.dev(sphi, "sphi", T.doubled_shape(g))
+        vx, vy, vz = _comps(g, vx, vy, vz, ("vx", "vy", "vz"))
+        eng = self._engine
+        with torch.cuda.device(self.vol.device):
+            torch.div(lvol, self.cell_vol * 0.125, out=self.vol)
+            self.x_x.copy_(vx)
+            self.x_y.copy_(vy)
+            self.x_z.copy_(vz)
+            _extrapolate_slab(g, 3, (self.x_x, self.x_y, self.x_z), sphi, self._cg)
+            initialize_solver(g, scale, mu, self.x_x, self.x_y, self.x_z, sphi, sv, self.vol,
+                              self.b_x, self.b_y, self.b_z)
+            # ghost planes carry no equation on this rank (their rows belong to the neighbour)
+            if self.part.right is not None:
+                self.b_x[L - 1].zero_()
+            for t in (self.b_y, self.b_z):
+                t[0].zero_()
+                t[L - 1].zero_()
+            eng.setup(scale, mu, sphi, self.vol)
+            f = self._flat
+            f["q"].zero_()
+            eng.bind(f["b"], f["x"], f["d"], f["r"], f["q"])
+            ok, self.iterations = self._cg.solve(tol, self.max_iter, self.check_every)
+            st = eng.poll()
+            self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
+            if not ok:
+                raise ValueError("Failed to converge!")
+            apply_viscosity(g, vx, vy, vz, self.x_x, self.x_y, self.x_z, sphi, sv)

@@ -41,6 +41,26 @@ def solver_mode(rank, world, path, out, dtname, dev):
     s.close()
 
 
+def viscosity_mode(rank, world, path, out, dtname, dev):
+    """SlabViscosityCGSolver3D.solve on this rank's slab of a golden viscosity scene (collectives over gloo)."""
+    from solver.ViscosityCGSolver3D import SlabViscosityCGSolver3D
+    with np.load(path, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    gres = tuple(int(v) for v in g["gres"])
+    s = SlabViscosityCGSolver3D(gres, g["bound_size"], dist, precision={"f64": "fp64", "f32": "fp32"}[dtname], device=dev)
+    lo, hi = s.part.local_range
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    vx, vy, vz = T(g["in_vx"][lo:hi + 1]), T(g["in_vy"][lo:hi]), T(g["in_vz"][lo:hi])
+    s.solve(float(g["dt"]), float(g["mu"]), float(g["rho"]), vx, vy, vz, T(g["sphi"][2 * lo:2 * hi + 1]),
+            T(g["sv"][2 * lo:2 * hi + 1]), T(g["lphi"][lo:hi]), T(g["lvol"][2 * lo:2 * hi + 1]), tol=float(g["tol"]))
+    torch.cuda.synchronize()
+    c = lambda t: t.cpu().numpy().astype(np.float64)  # noqa: E731
+    np.savez(f"{out}.rank{rank}.npz", vx=vx.cpu().numpy(), vy=vy.cpu().numpy(), vz=vz.cpu().numpy(),
+             x_x=c(s.x_x), x_y=c(s.x_y), x_z=c(s.x_z), b_x=c(s.b_x), b_y=c(s.b_y), b_z=c(s.b_z),
+             q_x=c(s.q_x), r_x=c(s.r_x), q_y=c(s.q_y), r_y=c(s.r_y),
+             hist=s.history, iters=s.iterations, lo=lo, hi=hi)
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     path, out, dtname = sys.argv[4], sys.argv[5], sys.argv[6]
@@ -74,6 +94,12 @@ def main():
                 with open(f"{out}.rank0.txt", "w") as f:
                     f.write(f"{_t.perf_counter() - t0:.3f}\n{outcome}\n")
             win.close()
+        finally:
+            dist.destroy_process_group()
+        return
+    if os.environ.get("P2P_TEST_MODE") == "viscosity":
+        try:
+            viscosity_mode(rank, world, path, out, dtname, dev)
         finally:
             dist.destroy_process_group()
         return

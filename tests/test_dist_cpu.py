@@ -93,3 +93,46 @@ def test_slab_cg_matches_single_domain(world, overlap, all_fluid):
         lo, hi = int(o["lo"]), int(o["hi"])
         # owned planes AND the ghost planes (x ghosts accumulate the neighbour's update)
         np.testing.assert_allclose(o["x"], ref["x"][lo:hi], rtol=0, atol=xtol * scale)
+
+
+@pytest.mark.parametrize("name,world", [("v3d_b_10x12x14", 2), ("v3d_a_12", 3)])
+def test_slab_viscosity_cg_matches_reference_golden(name, world):
+    """mfs.dist.SlabVCG (three staggered components, u-plane ownership, per-sweep ghost exchange of the extrapolation)
+    over gloo with the oracle as the local compute, against the golden outputs of the reference's own solve."""
+    import conftest
+    g = conftest.golden(name)
+    gpath = os.path.join(conftest.REPO, "tests", "golden", name + ".npz")
+    gres = tuple(int(v) for v in g["gres"])
+    Nx = gres[0]
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "problem.npz")
+        with open(gpath, "rb") as fi, open(path, "wb") as fo:
+            fo.write(fi.read())
+        mp.spawn(dist_worker.run_viscosity, args=(world, _free_port(), path, float(g["tol"]), 4000), nprocs=world,
+                 join=True)
+        outs = [dict(np.load(f"{path}.rank{r}.npz")) for r in range(world)]
+    asm = {k: [np.array(g[n]) for n in names] for k, names in
+           (("e", ("ex", "ey", "ez")), ("x", ("ex", "ey", "ez")), ("b", ("bx", "by", "bz")))}
+    for arr in asm["b"]:
+        arr[...] = 0.0
+    for o in outs:
+        lo, hi = int(o["lo"]), int(o["hi"])
+        L = hi - lo
+        assert int(o["done"]) == 1
+        top_u = L if hi == Nx else L - 1
+        if hi != Nx:
+            assert not o["q_x"][L - 1].any() and not o["r_x"][L - 1].any()
+        for c in "yz":
+            assert not o[f"q_{c}"][0].any() and not o[f"q_{c}"][L - 1].any() and not o[f"r_{c}"][0].any()
+        for k in ("e", "x", "b"):
+            asm[k][0][lo + 1:lo + top_u] = o[f"{k}_x"][1:top_u]
+            asm[k][1][lo + 1:hi - 1] = o[f"{k}_y"][1:L - 1]
+            asm[k][2][lo + 1:hi - 1] = o[f"{k}_z"][1:L - 1]
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o["hist"], outs[0]["hist"])
+    for k, names in (("e", ("ex", "ey", "ez")), ("b", ("bx", "by", "bz")), ("x", ("x_x", "x_y", "x_z"))):
+        scale = max(np.abs(g[n]).max() for n in names)
+        for arr, n in zip(asm[k], names):
+            np.testing.assert_allclose(arr, g[n], rtol=0, atol=(1e-10 if k == "x" else 1e-13) * scale, err_msg=n)
+    assert int(outs[0]["iters"]) == int(g["iters"])
+    np.testing.assert_allclose(outs[0]["hist"], g["history"], rtol=1e-9)

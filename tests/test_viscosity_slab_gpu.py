@@ -1,0 +1,71 @@
+"""Slab-decomposed viscosity solve (solver.ViscosityCGSolver3D.SlabViscosityCGSolver3D, mfs/dist.py:SlabVCG) on ONE
+MI355X: 1, 2 and 3 ranks -- separate processes sharing the card, collectives over gloo (RCCL on a node) -- each
+solving its x-slab of a golden scene.  The assembled RHS, solution and written-back velocities are compared with
+the golden outputs of the reference's own `solve` on the whole grid, and the residual history with the golden one."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from test_p2p_gpu import _run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def _assemble(g, res):
+    """owned faces of every rank -> global arrays (faces no rank owns keep the golden INPUT values / zeros)"""
+    gres = tuple(int(v) for v in g["gres"])
+    Nx, Ny, Nz = gres
+    shp = [(Nx + 1, Ny, Nz), (Nx, Ny + 1, Nz), (Nx, Ny, Nz + 1)]
+    out = {}
+    for base, init in (("b", None), ("x", ("ex", "ey", "ez")), ("v", ("in_vx", "in_vy", "in_vz"))):
+        out[base] = [np.zeros(s) if init is None else np.array(g[k], dtype=np.float64) for s, k in
+                     zip(shp, init or (None,) * 3)]
+    last = max(int(r["hi"]) for r in res)
+    for r in res:
+        lo, hi = int(r["lo"]), int(r["hi"])
+        L = hi - lo
+        top_u = L if hi == last else L - 1          # the last rank owns its u plane L-1 (global face Nx-1)
+        for base, keys in (("b", ("b_x", "b_y", "b_z")), ("x", ("x_x", "x_y", "x_z")), ("v", ("vx", "vy", "vz"))):
+            out[base][0][lo + 1:lo + top_u] = r[keys[0]][1:top_u]
+            out[base][1][lo + 1:hi - 1] = r[keys[1]][1:L - 1]
+            out[base][2][lo + 1:hi - 1] = r[keys[2]][1:L - 1]
+    return out
+
+
+@pytest.mark.parametrize("name,world,dtname", [
+    ("v3d_a_12", 1, "f64"), ("v3d_a_12", 2, "f64"), ("v3d_b_10x12x14", 2, "f64"), ("v3d_b_10x12x14", 3, "f64"),
+    ("v3d_a_12", 3, "f32"), ("v3d_c_16_mu50", 2, "f64"),
+])
+def test_slab_viscosity_matches_reference_outputs(name, world, dtname, tmp_path):
+    g = golden(name)
+    res = _run_ranks(name, world, tmp_path, dtname, P2P_TEST_MODE="viscosity")
+    a = _assemble(g, res)
+    for r in res:          # ghost planes of q and r stay exactly 0: the local dot products count owned faces only
+        L = int(r["hi"]) - int(r["lo"])
+        if int(r["hi"]) != max(int(q["hi"]) for q in res):
+            assert not r["q_x"][L - 1].any() and not r["r_x"][L - 1].any() and not r["b_x"][L - 1].any()
+        assert not r["q_x"][0].any() and not r["r_x"][0].any()
+        for k in ("q_y", "r_y", "b_y"):
+            assert not r[k][0].any() and not r[k][L - 1].any()
+    hists = [r["hist"] for r in res]
+    for h in hists[1:]:
+        np.testing.assert_array_equal(h, hists[0])        # every rank took the same all-reduced scalars
+    h, hg, it = hists[0], g["history"], int(g["iters"])
+    stable = "mu50" not in name
+    f64 = dtname == "f64"
+    bscale = max(np.abs(g[k]).max() for k in ("bx", "by", "bz"))
+    for arr, k in zip(a["b"], ("bx", "by", "bz")):
+        np.testing.assert_allclose(arr, g[k], rtol=0, atol=(1e-12 if f64 else 3e-6) * bscale, err_msg=k)
+    n = min(len(h), len(hg), 21 if f64 else 17)
+    np.testing.assert_allclose(h[:n], hg[:n], rtol=1e-9 if f64 else 1e-5)
+    if f64 and stable:
+        assert int(res[0]["iters"]) == it
+        np.testing.assert_allclose(h, hg, rtol=1e-9)
+    else:
+        assert 0.8 * it - 2 <= int(res[0]["iters"]) <= 1.5 * it + 2
+    vscale = max(np.abs(g[k]).max() for k in ("x_x", "x_y", "x_z"))
+    ftol = (1e-10 if f64 else 2e-5) if stable else 1e-3
+    for arr, k in zip(a["x"], ("x_x", "x_y", "x_z")):
+        np.testing.assert_allclose(arr, g[k], rtol=0, atol=ftol * vscale, err_msg=k)
+    for arr, k in zip(a["v"], ("out_vx", "out_vy", "out_vz")):
+        np.testing.assert_allclose(arr, g[k].astype(np.float64), rtol=0, atol=max(ftol, 1e-6) * vscale, err_msg=k)
