@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--n", type=int, default=0, help="override: cubic grid edge per GPU (default 256)")
+    ap.add_argument("--n", "--edge", dest="n", type=int, default=0, help="override: cubic grid edge per GPU (default 256)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the 256^3 grid is split over the ranks instead of 256^3 per rank")
     ap.add_argument("--local-grid", default="", help="1 GPU experiments: Nx,Ny,Nz of the grid (e.g. 66,512,512 = one rank's slab of the 8-GPU run)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -104,12 +104,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # MFS_BENCH_SHARED_GPU=1: REHEARSAL of the N > 1 flow on a one-GPU box -- every rank on cuda:0, gloo instead
+    # of RCCL (which refuses two ranks on one device).  The numbers mean nothing; the code path is the real one.
+    shared = os.environ.get("MFS_BENCH_SHARED_GPU", "0") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_phases or args.force_p2p:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mfs import _lib, scenes
     from mfs.pcg import PcgEngine
@@ -385,6 +393,8 @@ def main():
             "cg_iteration_hbm_gbs": round(iter_bytes / (dt / args.steps) / 1e9, 1),
             "roofline": rf,
         }
+        if shared:
+            out["rehearsal"] = "all ranks share cuda:0 over gloo (MFS_BENCH_SHARED_GPU=1): code-path check, not a measurement"
         if tinfo:
             out["transport_info"] = tinfo
         if cb is not None:

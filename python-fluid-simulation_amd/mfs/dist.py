@@ -85,15 +85,29 @@ class SlabCG:
         self.dist.all_reduce(self.ops.scalars[slot:slot + 1], group=self.group)
 
     def _halo_start(self):
-        dist, d, p = self.dist, self.d, self.part
+        """start the exchange of d's two edge planes; returns the function that completes it.  RCCL moves the device
+        planes themselves; any other backend (gloo in tests and rehearsals) gets host copies."""
+        dist, d, p, L = self.dist, self.d, self.part, self.L
+        staged = getattr(d, "is_cuda", False) and dist.get_backend(self.group) != "nccl"
+        src = {k: d[k].cpu() for k in (0, 1, L - 2, L - 1)} if staged else d
         ops = []
         if p.left is not None:
-            ops.append(dist.P2POp(dist.isend, d[1], p.left, self.group))
-            ops.append(dist.P2POp(dist.irecv, d[0], p.left, self.group))
+            ops.append(dist.P2POp(dist.isend, src[1], p.left, self.group))
+            ops.append(dist.P2POp(dist.irecv, src[0], p.left, self.group))
         if p.right is not None:
-            ops.append(dist.P2POp(dist.isend, d[self.L - 2], p.right, self.group))
-            ops.append(dist.P2POp(dist.irecv, d[self.L - 1], p.right, self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+            ops.append(dist.P2POp(dist.isend, src[L - 2], p.right, self.group))
+            ops.append(dist.P2POp(dist.irecv, src[L - 1], p.right, self.group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+
+        def finish():
+            for w in reqs:
+                w.wait()
+            if staged:
+                if p.left is not None:
+                    d[0].copy_(src[0])
+                if p.right is not None:
+                    d[L - 1].copy_(src[L - 1])
+        return finish
 
     def _p2p(self):
         """the window is usable for the engine as bound right now (else: the collective loop, on every rank alike --
@@ -123,19 +137,17 @@ class SlabCG:
             return
         L, ops = self.L, self.ops
         for _ in range(int(n)):
-            reqs = self._halo_start()
+            halo_done = self._halo_start()
             if self.overlap and L > 4:
                 ops.phase_apply(2, L - 2, True)      # planes that touch no ghost, while the halos fly
-                for w in reqs:
-                    w.wait()
+                halo_done()
                 if hasattr(ops, "phase_apply2"):
                     ops.phase_apply2(1, 2, L - 2, L - 1, False)      # both edge planes, one launch
                 else:
                     ops.phase_apply(1, 2, False)
                     ops.phase_apply(L - 2, L - 1, False)
             else:
-                for w in reqs:
-                    w.wait()
+                halo_done()
                 ops.phase_apply(1, L - 1, True)
             ops.phase_reduce(0)
             self._allreduce(_lib.S_DQ)

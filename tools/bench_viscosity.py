@@ -28,9 +28,16 @@ a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 eng.apply(f["d"], f["q"]); a.record()
 for _ in range(50): eng.apply(f["d"], f["q"])
 e.record(); torch.cuda.synchronize(); t_ap = a.elapsed_time(e) / 50 * 1e-3
+# the slab-decomposed loop's per-iteration kernels on this one GPU (1 rank: no exchange, no all-reduce -- what the
+# multi-GPU loop costs before its collectives): apply, 2 reductions, x/r update, direction update as separate phases
+from mfs.dist import SlabPartition, SlabVCG
+cgs = SlabVCG(eng, SlabPartition(N, 1, 0), (s.d_x, s.d_y, s.d_z))
+cgs.begin(0.0); cgs.iterate(10); torch.cuda.synchronize()
+t0 = time.perf_counter(); cgs.iterate(iters); torch.cuda.synchronize(); t_slab = (time.perf_counter() - t0) / iters
 cells = N ** 3
 out = {"workload": f"ViscosityCGSolver3D {N}^3 {dts}", "solve_iterations": s.iterations, "solve_s": round(t_solve, 4),
        "iter_us": round(t_it * 1e6, 2), "iters_per_s": round(1 / t_it, 1), "Mcells_per_s": round(cells / t_it / 1e6, 1),
        "iter_GBs_alg(43N^3)": round(43 * cells * esz / t_it / 1e9, 1),
+       "slab_phase_loop_iter_us": round(t_slab * 1e6, 2),
        "apply_us": round(t_ap * 1e6, 2), "apply_GBs_alg(16N^3)": round(16 * cells * esz / t_ap / 1e9, 1)}
 print(json.dumps(out))
