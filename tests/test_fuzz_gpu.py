@@ -1,6 +1,7 @@
 """Randomised shapes and scenes: the optimised native loop (LDS march with compressed coefficients, fused
 direction update, prefetch depth 2) against the same march with every one of those switched off (dense
-coefficients, direction update as its own kernel, depth 1) -- bit for bit, since the per-block partial
+coefficients, direction update as its own kernel, depth 1) and against the loop with the solution update deferred
+into the next stencil launch -- bit for bit, since the per-block partial
 sums are grouped identically -- and against the oracle on the first iterations.  (The direct-load
 variant 0 groups its dot-product partials differently, so it is compared on the stencil output only,
 tests/test_pressure_gpu.py / test_edge_cases_gpu.py.)  Shapes include odd sizes (scalar kernels), rows longer than
@@ -31,24 +32,27 @@ def test_optimised_loop_equals_plain_loop(gres, prec):
     seed = sum(gres)
     sc = scenes.pressure_scene_3d(gres, seed=seed, vel_dtype=np.float32, solid_velocity=bool(seed & 1))
     res = []
-    for plain in (False, True):
+    for mode in ("optimised", "plain", "deferred_x"):
         buf = B.CGSolverBuffer(gres, precision=prec, device=DEV)
         s = P.PressureCGSolver3D(buf, gres, sc["bound_size"], check_every=3)
         s.max_iter = 12                                  # a dozen iterations exercise every pipeline stage
         e = s._engine
-        if plain:
+        if mode == "plain":
             e.set_compress(False); e.set_fuse(False); e.set_prefetch(1)
+        if mode == "deferred_x":                         # x += alpha d rides in the NEXT stencil launch (default only
+            e.set_defer_x(True)                          # beyond the Infinity Cache; forced here), flushed at the end
         v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
         try:
             s.solve(*v, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]), tol=1e-30)
         except ValueError:
             pass                                         # "Failed to converge!" after max_iter, as intended
         res.append((s.iterations, s.history, s.x.clone(), buf.d.clone(), buf.r.clone(), buf.q.clone()))
-    a, b = res
-    assert a[0] == b[0]
-    np.testing.assert_array_equal(a[1], b[1])
-    for i in range(2, 6):
-        assert torch.equal(a[i], b[i]), ("x", "d", "r", "q")[i - 2]
+    a = res[0]
+    for b in res[1:]:
+        assert a[0] == b[0]
+        np.testing.assert_array_equal(a[1], b[1])
+        for i in range(2, 6):
+            assert torch.equal(a[i], b[i]), ("x", "d", "r", "q")[i - 2]
     if prec == "fp64" and min(gres) >= 3:
         ref = O.PressureCGSolver3D(gres, sc["bound_size"])
         rv = [sc["vx"].copy(), sc["vy"].copy(), sc["vz"].copy()]

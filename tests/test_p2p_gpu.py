@@ -100,6 +100,25 @@ def test_slab_p2p_matches_single_domain(name, world, dtname, tmp_path):
         np.testing.assert_allclose(x, x0, rtol=0, atol=1e-3 * np.abs(x0).max())
 
 
+@pytest.mark.parametrize("name,world", [("p3d_d_20", 2), ("p3d_d_20", 3), ("p3d_a_12", 5)])
+def test_slab_p2p_deferred_x_update(name, world, tmp_path):
+    """the slab loop with the solution update deferred into the next iteration's edge / interior launches (its default
+    on production-size slabs, forced here): same history bit for bit, same solution as the undeferred loop."""
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    out = {}
+    for defer in ("0", "1"):
+        res = _run_ranks(name, world, tmp_path, "f64", MFS_DEFER_X=defer)
+        x = np.zeros(gres)
+        for r in res:
+            lo, hi = int(r["lo"]), int(r["hi"])
+            x[lo + 1:hi - 1] = r["x"][1:-1]
+        out[defer] = (res[0]["hist"], x, int(res[0]["iters"]))
+    np.testing.assert_array_equal(out["0"][0], out["1"][0])
+    assert out["0"][2] == out["1"][2]
+    np.testing.assert_array_equal(out["0"][1], out["1"][1])
+
+
 @pytest.mark.parametrize("name,world", [("p3d_d_20", 2), ("p3d_b_10x12x14_sv", 2), ("p3d_d_20", 3)])
 def test_slab_solver_class_matches_reference_outputs(name, world, tmp_path):
     """SlabPressureCGSolver3D.solve (the reference's solve signature on a rank's slab): RHS, pressure and the
