@@ -166,7 +166,12 @@ def test_lost_peer_is_reported_not_hung(tmp_path):
     env = dict(os.environ, MFS_P2P_TIMEOUT_MS="400", P2P_TEST_MODE="lost_peer")
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", str(port), "-", out, "f64"], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    logs = [p.communicate(timeout=120)[0] for p in procs]
+    try:
+        logs = [p.communicate(timeout=120)[0] for p in procs]
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        raise
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
     secs, outcome = open(out + ".rank0.txt").read().strip().split("\n")
     assert outcome.startswith("MfsError") and "status -4" in outcome and "timed out" in outcome, outcome
