@@ -6,7 +6,8 @@ runs as HIP kernels behind the C ABI (SURVEY.md 8(f) ranks 1-4 around the two ho
 This is the driver a user of the reference's notebook switches to: same containers (attribute names of
 its `edict`s), same dtypes (bounds / biases float32, cell sizes float64, particle arrays float64, grid mass
 and velocity float32, level sets float64), same call order with the `solver='apic'` branch (the U-Net
-branch needs a checkpoint that is a remote download).  Single GPU.
+branch needs a checkpoint that is a remote download, SURVEY.md 2).  `NotebookSimulation`: single GPU;
+`SlabNotebookSimulation`: one process per GPU, the two hot-path CG solves slab-decomposed (BASELINE config 5).
 """
 import time
 import types
@@ -18,8 +19,8 @@ import notebook_kernels as K
 from solver import sdf3D as sdf
 from solver.CGSolverBuffer import CGSolverBuffer
 from solver.DensityCGSolver3D import DensityCGSolver3D
-from solver.PressureCGSolver3D import PressureCGSolver3D
-from solver.ViscosityCGSolver3D import ViscosityCGSolver3D
+from solver.PressureCGSolver3D import PressureCGSolver3D, SlabPressureCGSolver3D
+from solver.ViscosityCGSolver3D import SlabViscosityCGSolver3D, ViscosityCGSolver3D
 
 NS = types.SimpleNamespace
 
@@ -76,12 +77,28 @@ class NotebookSimulation:
                                  phi=torch.zeros(g, dtype=torch.float64, device=dev))
         self.fluid_volume = NS(resolution=dres, bound_size=bsz, bound_min=bmin, cell_size=dcs,
                                vol=torch.zeros(dres, dtype=torch.float64, device=dev))
-        self.CGBuf = CGSolverBuffer(g, precision=precision, device=dev)
-        self.PressureSolver = PressureCGSolver3D(self.CGBuf, g, gdx)
-        self.DensitySolver = DensityCGSolver3D(self.CGBuf, g, bmin, bsz)
-        self.ViscositySolver = ViscosityCGSolver3D(g, bsz, precision=precision, device=dev)
+        self._precision = precision
+        self._make_solvers()
         self.current_time = 0.0
         self.iterations = 0
+
+    def _make_solvers(self):
+        """CGBuf / PressureSolver / DensitySolver / ViscositySolver of code cell 9 (ipynb:777-780)."""
+        g, dev = self.GRES, self.device
+        self.CGBuf = CGSolverBuffer(g, precision=self._precision, device=dev)
+        self.PressureSolver = PressureCGSolver3D(self.CGBuf, g, self.GDX)
+        self.DensitySolver = DensityCGSolver3D(self.CGBuf, g, self.BOUND_MIN, self.BOUND_SIZE)
+        self.ViscositySolver = ViscosityCGSolver3D(g, self.BOUND_SIZE, precision=self._precision, device=dev)
+
+    def _solve_grid(self, dt, tick, t):
+        """the two hot-path solves of the loop body (ipynb:4623, 4648) on the grid velocities, in place"""
+        g, sl, fl, fv = self.grid, self.solid_levelset, self.fluid_levelset, self.fluid_volume
+        if self.MU > 0:
+            self.ViscositySolver.solve(dt, self.MU, self.RHO, g.x.v, g.y.v, g.z.v, sl.phi, sl.v, fl.phi, fv.vol)
+        t = tick("viscosity", t)
+        ds = self.DensitySolver
+        self.PressureSolver.solve(g.x.v, g.y.v, g.z.v, sl.phi, sl.v, fl.phi, wx=ds.wx, wy=ds.wy, wz=ds.wz)
+        return tick("pressure", t)
 
     def step(self, duration_left=float("inf"), timings=None):
         """One pass of the loop body (ipynb:4571-4667, solver == 'apic').  Returns the dt it took."""
@@ -115,12 +132,7 @@ class NotebookSimulation:
         K.p2g(p, g)
         g.y.v += -10 * dt                                                   # gravity
         t = tick("p2g", t)
-        if self.MU > 0:
-            self.ViscositySolver.solve(dt, self.MU, self.RHO, g.x.v, g.y.v, g.z.v, sl.phi, sl.v, fl.phi, fv.vol)
-        t = tick("viscosity", t)
-        ds = self.DensitySolver
-        self.PressureSolver.solve(g.x.v, g.y.v, g.z.v, sl.phi, sl.v, fl.phi, wx=ds.wx, wy=ds.wy, wz=ds.wz)
-        t = tick("pressure", t)
+        t = self._solve_grid(dt, tick, t)
         K.extrapolate(self.GRES, 2, g.x.v, g.y.v, g.z.v, g.x.m, g.y.m, g.z.m)
         K.apply_boundary_condition(g, sl, self.GDX)
         t = tick("extrapolate+bc", t)
@@ -128,6 +140,64 @@ class NotebookSimulation:
         tick("g2p", t)
         self.iterations += 1
         return dt
+
+
+class SlabNotebookSimulation(NotebookSimulation):
+    """The same time step on N GPUs, one process per GPU (extension; BASELINE config 5 names 4 GPUs).
+
+    What is sharded: the viscosity CG and the pressure CG -- 85 % of a 256^3 step on one GPU --
+    run slab-decomposed along x on this rank's planes (`SlabViscosityCGSolver3D`, `SlabPressureCGSolver3D`: halo planes
+    and dot products over xGMI).  What is replicated: the particle stages, the density solve and the small grid
+    stages (advect, project, level set / volume, p2g, extrapolate, boundary condition, g2p) -- every rank holds all
+    particles and the full grids for them.  Their atomics make the replicas differ in the last bits, so rank 0's grid
+    state is broadcast before the solves (one source of truth for every slab and its ghost planes), and the solved
+    velocities are gathered back (each rank broadcasts its owned planes) for the replicated stages that follow.
+    Amdahl: with fractions f of a one-GPU step in the two solves the step takes (1 - f) + f / N; sharding the density
+    solve and the particles (migration between slabs) is the next step.  `step` is collective."""
+
+    def __init__(self, *args, dist, group=None, transport="auto", **kw):
+        self.dist, self.group, self._transport = dist, group, transport
+        super().__init__(*args, **kw)
+
+    def _make_solvers(self):
+        from mfs.dist import SlabPartition
+        g, dev, dist, group = self.GRES, self.device, self.dist, self.group
+        self.CGBuf = CGSolverBuffer(g, precision=self._precision, device=dev)            # density solve (replicated)
+        self.DensitySolver = DensityCGSolver3D(self.CGBuf, g, self.BOUND_MIN, self.BOUND_SIZE)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.part = SlabPartition(g[0], self.world, self.rank)
+        lg = SlabPressureCGSolver3D.local_gres(g, self.world, self.rank)
+        self._slab_buf = CGSolverBuffer(lg, precision=self._precision, device=dev)
+        self.PressureSolver = SlabPressureCGSolver3D(self._slab_buf, g, self.GDX, dist, group, transport=self._transport)
+        self.ViscositySolver = SlabViscosityCGSolver3D(g, self.BOUND_SIZE, dist, group, precision=self._precision, device=dev)
+
+    def _solve_grid(self, dt, tick, t):
+        from mfs.dist import SlabPartition
+        g, sl, fl, fv, ds = self.grid, self.solid_levelset, self.fluid_levelset, self.fluid_volume, self.DensitySolver
+        dist, group = self.dist, self.group
+        if self.world > 1:
+            for a in (g.x.v, g.y.v, g.z.v, fl.phi, fv.vol, ds.wx, ds.wy, ds.wz):
+                dist.broadcast(a, src=0, group=group)
+        t = tick("broadcast", t)
+        lo, hi = self.part.local_range
+        vx, vy, vz = g.x.v[lo:hi + 1], g.y.v[lo:hi], g.z.v[lo:hi]            # views: the solves update the planes in place
+        sphi, sv, lphi = sl.phi[2 * lo:2 * hi + 1], sl.v[2 * lo:2 * hi + 1], fl.phi[lo:hi]
+        if self.MU > 0:
+            self.ViscositySolver.solve(dt, self.MU, self.RHO, vx, vy, vz, sphi, sv, lphi, fv.vol[2 * lo:2 * hi + 1])
+        t = tick("viscosity", t)
+        self.PressureSolver.solve(vx, vy, vz, sphi, sv, lphi, wx=ds.wx[lo:hi + 1], wy=ds.wy[lo:hi], wz=ds.wz[lo:hi])
+        t = tick("pressure", t)
+        if self.world > 1:       # every rank's owned planes -> every rank (the last rank also owns the planes up to Nx-1)
+            for r in range(self.world):
+                a, b = SlabPartition(self.GRES[0], self.world, r).owned
+                if r == self.world - 1:
+                    b += 1
+                for arr in (g.x.v, g.y.v, g.z.v):
+                    dist.broadcast(arr[a:b], src=r, group=group)
+        return tick("gather", t)
+
+    def close(self):
+        self.PressureSolver.close()
 
 
 def add_box(center, size, dx, rng, keep=None):

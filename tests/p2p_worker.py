@@ -61,6 +61,35 @@ def viscosity_mode(rank, world, path, out, dtname, dev):
              hist=s.history, iters=s.iterations, lo=lo, hi=hi)
 
 
+def timestep_mode(rank, world, path, out, dtname, dev):
+    """SlabNotebookSimulation: whole time steps with the two hot-path solves slab-decomposed (BASELINE config 5)."""
+    import notebook_sim as NSIM
+    import solver.sdf3D as sdf
+    with np.load(path, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    gres = tuple(int(v) for v in g["gres"])
+    gdx = float(g["gdx"])
+    size = np.array(gres) * gdx
+    rb_d, rb_map = sdf.generate_rb(None, {}, 'cube', ['box', size[0] - 2 * gdx, size[1] - 2 * gdx, size[2] - 2 * gdx], flip=True,
+                                   center=[0, size[1] / 2, 0], axis=[0., 1, 0], angle=0, device=dev)
+    rb_d, rb_map = sdf.generate_rb(rb_d, rb_map, 'ramp', ['box', 0.45, 0.05, 0.8], flip=False, center=[-0.12, 0.2, 0],
+                                   axis=[0., 0, 1], angle=-35)
+    sim = NSIM.SlabNotebookSimulation(gres, gdx, [-0.3, 0, -0.3], rb_d, g["px0"], float(g["pdx"]), rho=float(g["rho"]),
+                                      mu=float(g["mu"]), dt=float(g["dt"]), device=dev, dist=dist,
+                                      transport=os.environ.get("P2P_TEST_TRANSPORT", "auto"))
+    sim.particle.v.copy_(torch.as_tensor(g["pv0"], device=dev))
+    res, timings = {}, {}
+    for s in range(int(g["steps"])):
+        res[f"dt{s + 1}"] = sim.step(timings=timings)
+        res[f"px{s + 1}"] = sim.particle.x.cpu().numpy()
+        res[f"pv{s + 1}"] = sim.particle.v.cpu().numpy()
+        res[f"lphi{s + 1}"] = sim.fluid_levelset.phi.cpu().numpy()
+        res[f"gvy{s + 1}"] = sim.grid.y.v.cpu().numpy()
+    np.savez(f"{out}.rank{rank}.npz", transport=sim.PressureSolver.transport, p_iters=sim.PressureSolver.iterations,
+             v_iters=sim.ViscositySolver.iterations, stages=np.array(sorted(timings)), **res)
+    sim.close()
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     path, out, dtname = sys.argv[4], sys.argv[5], sys.argv[6]
@@ -94,6 +123,12 @@ def main():
                 with open(f"{out}.rank0.txt", "w") as f:
                     f.write(f"{_t.perf_counter() - t0:.3f}\n{outcome}\n")
             win.close()
+        finally:
+            dist.destroy_process_group()
+        return
+    if os.environ.get("P2P_TEST_MODE") == "timestep":
+        try:
+            timestep_mode(rank, world, path, out, dtname, dev)
         finally:
             dist.destroy_process_group()
         return

@@ -54,3 +54,27 @@ def test_two_full_steps():
         np.testing.assert_allclose(N(sim.grid.y.v), gvy, rtol=0, atol=5e-3 * np.abs(gvy).max())
     assert sim.iterations == 2 and set(timings) >= {"density", "viscosity", "pressure", "p2g", "g2p"}
     assert sim.PressureSolver.iterations > 0 and sim.ViscositySolver.iterations > 0 and sim.DensitySolver.iterations > 0
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_two_full_steps_slab_decomposed(world, tmp_path):
+    """BASELINE config 5 on N ranks (notebook_sim.SlabNotebookSimulation; the ranks are processes sharing the one GPU of
+    the box): viscosity and pressure CG slab-decomposed, the other stages replicated -- against the same goldens with
+    the same tolerances as the single-GPU step, and every rank ends the step with the same state."""
+    from test_p2p_gpu import _run_ranks
+    g = golden("step_a_12x16x12")
+    res = _run_ranks("step_a_12x16x12", world, tmp_path, "f64", P2P_TEST_MODE="timestep")
+    for r in res:
+        assert int(r["p_iters"]) > 0 and int(r["v_iters"]) > 0
+        assert {"viscosity", "pressure", "broadcast", "gather", "density", "p2g", "g2p"} <= set(str(x) for x in r["stages"])
+        for s in range(int(g["steps"])):
+            assert float(r[f"dt{s + 1}"]) == pytest.approx(float(g["dts"][s]), rel=1e-12)
+            move = np.abs(g[f"px{s + 1}"] - g["px0"]).max()
+            np.testing.assert_allclose(r[f"px{s + 1}"], g[f"px{s + 1}"], rtol=0, atol=1e-4 * move * (s + 1))
+            np.testing.assert_allclose(r[f"pv{s + 1}"], g[f"pv{s + 1}"], rtol=0, atol=2e-3 * np.abs(g[f"pv{s + 1}"]).max())
+            np.testing.assert_allclose(r[f"lphi{s + 1}"], g[f"lphi{s + 1}"], rtol=0, atol=1e-4 * float(g["gdx"]))
+            gvy = g[f"gvy{s + 1}"]
+            np.testing.assert_allclose(r[f"gvy{s + 1}"], gvy, rtol=0, atol=5e-3 * np.abs(gvy).max())
+    for r in res[1:]:       # the gathered grid velocities are the same arrays on every rank
+        for s in range(int(g["steps"])):
+            np.testing.assert_array_equal(r[f"gvy{s + 1}"], res[0][f"gvy{s + 1}"])

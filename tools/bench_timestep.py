@@ -1,7 +1,9 @@
 """GPU: whole time steps of the notebook's loop (BASELINE config 5's pipeline on ONE MI355X): a buckling-like
 scene scaled to an N^3 grid -- flipped container box, four slanted obstacle plates (ipynb code cell 9), a fluid
 block of (N/2)^3 cells at 8 particles per cell -- stepped with notebook_sim.NotebookSimulation; per-stage
-wall-clock (synchronised), CG iteration counts.   usage: python tools/bench_timestep.py [N] [steps] [mu]"""
+wall-clock (synchronised), CG iteration counts.   usage: python tools/bench_timestep.py [N] [steps] [mu]
+Under `python -m torch.distributed.run --nproc-per-node R ...` (one rank per GPU, RCCL) the two hot-path solves run
+slab-decomposed (notebook_sim.SlabNotebookSimulation); MFS_BENCH_SHARED_GPU=1 = rehearsal with all ranks on cuda:0 / gloo."""
 import json, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "python-fluid-simulation_amd"), REPO]
@@ -11,7 +13,18 @@ import solver.sdf3D as sdf
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mu = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
-dev = "cuda:0"
+world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+shared = os.environ.get("MFS_BENCH_SHARED_GPU", "0") == "1"
+dev = "cuda:0" if (world == 1 or shared) else f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+torch.cuda.set_device(dev)
+dist = None
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if shared:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 gdx = 1.0 / N
 size = np.array([1.0, 1.0, 1.0])
 bmin = [-0.5, 0.0, -0.5]
@@ -23,7 +36,11 @@ for nm, par, c, ax, ang in (("p1", ['box', 0.67, 0.05, 1.2], [-0.42, h, 0], [0, 
 rng = np.random.default_rng(0)
 t0 = time.perf_counter()
 px = NSIM.add_box([0.0, 0.7, 0.0], [0.5, 0.5, 0.5], gdx / 2, rng)
-sim = NSIM.NotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"))
+if dist is None:
+    sim = NSIM.NotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"))
+else:
+    sim = NSIM.SlabNotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev,
+                                      precision=os.environ.get("MFS_PRECISION"), dist=dist)
 sim.particle.v[:, 0] = -2.0
 torch.cuda.synchronize()
 t_setup = time.perf_counter() - t0
@@ -35,8 +52,19 @@ for _ in range(steps):
     its.append((sim.DensitySolver.iterations, sim.ViscositySolver.iterations, sim.PressureSolver.iterations))
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
-print(json.dumps({"workload": f"notebook time step {N}^3, {sim.particle.num_particles} particles, mu={mu}",
+if dist is not None:
+    tt = torch.tensor([t_all], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t_all = tt.item()
+if rank == 0:
+  print(json.dumps({"workload": f"notebook time step {N}^3, {sim.particle.num_particles} particles, mu={mu}",
+                  "ranks": world, "decomposition": "single GPU" if dist is None else
+                  f"viscosity + pressure CG on x-slabs x{world} ({sim.PressureSolver.transport}), other stages replicated"
+                  + (" [REHEARSAL: ranks share one GPU]" if shared else ""),
                   "state_precision": os.environ.get("MFS_PRECISION", "fp64"), "steps": steps,
                   "s_per_step": round(t_all / steps, 4), "setup_s": round(t_setup, 2),
                   "stage_ms_per_step": {k: round(v / steps * 1e3, 2) for k, v in tim.items()},
                   "cg_iterations(density,viscosity,pressure)": its}))
+if dist is not None:
+    sim.close()
+    dist.destroy_process_group()
