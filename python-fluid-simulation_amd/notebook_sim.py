@@ -18,7 +18,7 @@ import torch
 import notebook_kernels as K
 from solver import sdf3D as sdf
 from solver.CGSolverBuffer import CGSolverBuffer
-from solver.DensityCGSolver3D import DensityCGSolver3D
+from solver.DensityCGSolver3D import DensityCGSolver3D, SlabDensityCGSolver3D
 from solver.PressureCGSolver3D import PressureCGSolver3D, SlabPressureCGSolver3D
 from solver.ViscosityCGSolver3D import SlabViscosityCGSolver3D, ViscosityCGSolver3D
 
@@ -145,15 +145,15 @@ class NotebookSimulation:
 class SlabNotebookSimulation(NotebookSimulation):
     """The same time step on N GPUs, one process per GPU (extension; BASELINE config 5 names 4 GPUs).
 
-    What is sharded: the viscosity CG and the pressure CG -- 85 % of a 256^3 step on one GPU --
-    run slab-decomposed along x on this rank's planes (`SlabViscosityCGSolver3D`, `SlabPressureCGSolver3D`: halo planes
-    and dot products over xGMI).  What is replicated: the particle stages, the density solve and the small grid
-    stages (advect, project, level set / volume, p2g, extrapolate, boundary condition, g2p) -- every rank holds all
-    particles and the full grids for them.  Their atomics make the replicas differ in the last bits, so rank 0's grid
+    What is sharded: the three CG loops -- 98 % of a 256^3 step on one GPU -- run slab-decomposed
+    along x on this rank's planes (`SlabViscosityCGSolver3D`, `SlabPressureCGSolver3D`, `SlabDensityCGSolver3D`: halo
+    planes and dot products over xGMI).  What is replicated: the particle stages and the small grid stages (advect,
+    project, level set / volume, splat, p2g, extrapolate, boundary condition, g2p) -- every rank holds all particles
+    and the full grids for them.  Their atomics make the replicas differ in the last bits, so rank 0's grid
     state is broadcast before the solves (one source of truth for every slab and its ghost planes), and the solved
     velocities are gathered back (each rank broadcasts its owned planes) for the replicated stages that follow.
-    Amdahl: with fractions f of a one-GPU step in the two solves the step takes (1 - f) + f / N; sharding the density
-    solve and the particles (migration between slabs) is the next step.  `step` is collective."""
+    Amdahl: with the fraction f of a one-GPU step in the three loops the step takes (1 - f) + f / N; sharding the
+    particles (migration between slabs) is the next step.  `step` is collective."""
 
     def __init__(self, *args, dist, group=None, transport="auto", **kw):
         self.dist, self.group, self._transport = dist, group, transport
@@ -162,8 +162,8 @@ class SlabNotebookSimulation(NotebookSimulation):
     def _make_solvers(self):
         from mfs.dist import SlabPartition
         g, dev, dist, group = self.GRES, self.device, self.dist, self.group
-        self.CGBuf = CGSolverBuffer(g, precision=self._precision, device=dev)            # density solve (replicated)
-        self.DensitySolver = DensityCGSolver3D(self.CGBuf, g, self.BOUND_MIN, self.BOUND_SIZE)
+        self.CGBuf = CGSolverBuffer(g, precision=self._precision, device=dev)            # the density solve's global RHS
+        self.DensitySolver = SlabDensityCGSolver3D(self.CGBuf, g, self.BOUND_MIN, self.BOUND_SIZE, dist, group)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.part = SlabPartition(g[0], self.world, self.rank)
         lg = SlabPressureCGSolver3D.local_gres(g, self.world, self.rank)

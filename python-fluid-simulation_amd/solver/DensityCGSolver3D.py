@@ -171,3 +171,66 @@ class DensityCGSolver3D:
             apply_displacement(px, self.dx, self.bound_min, self.cell_size, self.bias_x, 0)
             apply_displacement(px, self.dy, self.bound_min, self.cell_size, self.bias_y, 1)
             apply_displacement(px, self.dz, self.bound_min, self.cell_size, self.bias_z, 2)
+
+
+class SlabDensityCGSolver3D(DensityCGSolver3D):
+    """`DensityCGSolver3D` on N GPUs with REPLICATED particles (extension; one process per GPU): same constructor
+    arguments plus `dist`, same `solve` signature on the GLOBAL arrays.  The CG loop -- all but a few milliseconds of the
+    solve -- runs slab-decomposed along x (`mfs.dist.SlabCG`, collectives per iteration: the operator is the pressure
+    stencil with the asymmetric -z tap, which the window kernels do not carry yet); the particle splat, `fix_volume`,
+    the RHS, the displacement and the particle update run replicated on every rank, exactly as on one GPU.  The splat's
+    atomics make the replicas differ in the last bits, so rank 0's RHS is broadcast (one source of truth), and every rank
+    receives every rank's owned planes of the solution.  Collective."""
+
+    def __init__(self, buf, gres, bound_min, bound_size, dist, group=None, check_every=32):
+        from mfs.dist import SlabCG, SlabPartition
+        super().__init__(buf, gres, bound_min, bound_size, check_every)
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        g = self._g
+        self.part = SlabPartition(g[0], self.world, self.rank)
+        lo, hi = self.part.local_range
+        lg = (hi - lo, g[1], g[2])
+        dt, device = buf.b.dtype, buf.b.device
+        self._lb, self._lx, self._ld, self._lr, self._lq = (torch.zeros(lg, dtype=dt, device=device) for _ in range(5))
+        self._engine = PcgEngine(lg, dt, device)          # replaces the full-grid engine
+        self._cg = SlabCG(self._engine, self.part, self._ld, dist, group, force_multi=True)
+
+    def solve(self, rho0, dt, px, pm, pvol, vx, vy, vz, sphi, sv, lphi, lvol, wx=None, wy=None, wz=None, tol=1e-3):
+        from mfs.dist import SlabPartition
+        g = self._g
+        if wx is None or wy is None or wz is None:
+            compute_solid_frac(self.gres, sphi, self.wx, self.wy, self.wz)
+            wx, wy, wz = self.wx, self.wy, self.wz
+        eng, dist, group = self._engine, self.dist, self.group
+        lo, hi = self.part.local_range
+        lphi = T.dev(lphi, "lphi", g)
+        wx, wy, wz = _faces(g, wx, wy, wz)
+        with torch.cuda.device(self.x.device):
+            self.m *= 0
+            self.vol *= 0
+            initialize_density(self.bound_min, self.cell_size, g, px, pm, pvol, self.m, self.vol, sphi, lphi)
+            fix_volume(self.cell_size, g, lvol, self.vol, sphi, lphi, wx, wy, wz)
+            initialize_solver(rho0, dt, g, self.cell_size, self.m, self.vol, lphi, wx, wy, wz, self.buf.b)
+            if self.world > 1:
+                dist.broadcast(self.buf.b, src=0, group=group)
+            self._lb.copy_(self.buf.b[lo:hi])
+            self._lb[0].zero_()          # ghost / boundary planes carry no equation on this rank
+            self._lb[-1].zero_()
+            eng.setup_density(lphi[lo:hi], wx[lo:hi + 1], wy[lo:hi], wz[lo:hi])
+            eng.bind(self._lb, self._lx, self._ld, self._lr, self._lq)
+            ok, self.iterations = self._cg.solve(tol, self.max_iter, self.check_every)
+            st = eng.poll()
+            self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
+            if not ok:
+                raise ValueError("Failed to converge!")
+            self.x.zero_()
+            self.x[lo + 1:hi - 1] = self._lx[1:-1]
+            if self.world > 1:
+                for r in range(self.world):
+                    a, b = SlabPartition(g[0], self.world, r).owned
+                    dist.broadcast(self.x[a:b], src=r, group=group)
+            compute_displacement(g, dt, self.cell_size, self.dx, self.dy, self.dz, self.x, lphi)
+            apply_displacement(px, self.dx, self.bound_min, self.cell_size, self.bias_x, 0)
+            apply_displacement(px, self.dy, self.bound_min, self.cell_size, self.bias_y, 1)
+            apply_displacement(px, self.dz, self.bound_min, self.cell_size, self.bias_z, 2)

@@ -61,6 +61,25 @@ def viscosity_mode(rank, world, path, out, dtname, dev):
              hist=s.history, iters=s.iterations, lo=lo, hi=hi)
 
 
+def density_mode(rank, world, path, out, dtname, dev):
+    """SlabDensityCGSolver3D.solve (replicated particles, CG loop slab-decomposed) on a golden density scene."""
+    from solver.CGSolverBuffer import CGSolverBuffer
+    from solver.DensityCGSolver3D import SlabDensityCGSolver3D
+    with np.load(path, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    gres = tuple(int(v) for v in g["gres"])
+    buf = CGSolverBuffer(gres, precision={"f64": "fp64", "f32": "fp32"}[dtname], device=dev)
+    s = SlabDensityCGSolver3D(buf, gres, g["bound_min"], g["bound_size"], dist)
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    px = T(g["px"])
+    s.solve(float(g["rho0"]), float(g["dt"]), px, T(g["pm"]), float(g["pvol"]), None, None, None, T(g["sphi"]), T(g["sv"]),
+            T(g["lphi"]), T(g["lvol"]), tol=float(g["tol"]))
+    torch.cuda.synchronize()
+    c = lambda t: t.cpu().numpy().astype(np.float64)  # noqa: E731
+    np.savez(f"{out}.rank{rank}.npz", px=c(px), x=c(s.x), dx=c(s.dx), dy=c(s.dy), dz=c(s.dz), hist=s.history,
+             iters=s.iterations, delta=s.delta, lq=c(s._lq), lr=c(s._lr))
+
+
 def timestep_mode(rank, world, path, out, dtname, dev):
     """SlabNotebookSimulation: whole time steps with the two hot-path solves slab-decomposed (BASELINE config 5)."""
     import notebook_sim as NSIM
@@ -123,6 +142,12 @@ def main():
                 with open(f"{out}.rank0.txt", "w") as f:
                     f.write(f"{_t.perf_counter() - t0:.3f}\n{outcome}\n")
             win.close()
+        finally:
+            dist.destroy_process_group()
+        return
+    if os.environ.get("P2P_TEST_MODE") == "density":
+        try:
+            density_mode(rank, world, path, out, dtname, dev)
         finally:
             dist.destroy_process_group()
         return

@@ -116,3 +116,26 @@ def test_density_weights_feed_the_pressure_solve():
     vx, vy, vz = T(p["in_vx"]), T(p["in_vy"]), T(p["in_vz"])
     ps.solve(vx, vy, vz, T(p["sphi"]), T(p["sv"]), T(p["lphi"]), wx=ds.wx, wy=ds.wy, wz=ds.wz)
     assert ps.iterations > 0 and ps.delta < 1e-6
+
+
+@pytest.mark.parametrize("name,world", [("d3d_a_12", 2), ("d3d_a_12", 3), ("d3d_b_10x12x14_f32", 2)])
+def test_slab_density_solver_matches_reference(name, world, tmp_path):
+    """SlabDensityCGSolver3D (replicated particles, CG loop slab-decomposed over `world` processes sharing the GPU):
+    history, solution, displacements and moved particles against the goldens of the reference's own solve."""
+    from test_p2p_gpu import _run_ranks
+    g = golden(name)
+    res = _run_ranks(name, world, tmp_path, "f64", P2P_TEST_MODE="density")
+    for r in res:
+        h = r["hist"]
+        n = min(21, len(h), len(g["history"]))
+        np.testing.assert_allclose(h[:n], g["history"][:n], rtol=1e-9)
+        assert abs(int(r["iters"]) - int(g["iters"])) <= max(2, int(g["iters"]) // 10)
+        assert float(r["delta"]) < float(g["tol"]) ** 2
+        assert not r["lq"][0].any() and not r["lq"][-1].any() and not r["lr"][0].any() and not r["lr"][-1].any()
+        np.testing.assert_allclose(r["x"], g["x"], rtol=0, atol=1e-6 * np.abs(g["x"]).max())
+        for k in ("dx", "dy", "dz"):
+            np.testing.assert_allclose(r[k], g[k], rtol=0, atol=1e-6 * np.abs(g[k]).max())
+        np.testing.assert_allclose(r["px"], g["out_px"], rtol=0, atol=1e-6 * np.abs(g["out_px"] - g["px"]).max() + 1e-7)
+    for r in res[1:]:
+        np.testing.assert_array_equal(r["hist"], res[0]["hist"])
+        np.testing.assert_array_equal(r["x"], res[0]["x"])
