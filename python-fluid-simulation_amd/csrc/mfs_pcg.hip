@@ -774,7 +774,7 @@ int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_strea
 // Slab loop over peer-to-peer windows (mfs_pcg_slab.h): one rank of a grid cut into x-slabs.
 // ----------------------------------------------------------------------------------------------
 static bool slab_ok(const mfs_pcg3d* h) {
-  return h->p2p && h->p2p->connected && native_fuse_ok(h) && !h->asym && !h->jacobi &&
+  return h->p2p && h->p2p->connected && native_fuse_ok(h) && !h->jacobi &&
          (size_t)h->Ny * h->Nz * h->c.elt == h->p2p->plane_bytes;
 }
 
@@ -834,7 +834,8 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     const int64_t items = (int64_t)e.np * (h->Ny - 2) * (h->Nz / VEC);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (items + kApplyBlock - 1) / kApplyBlock));
     hipLaunchKernelGGL((k_slab_edge_apply<T, VEC>), dim3(grid), dim3(kApplyBlock), 0, st, (const T*)d_cur, (T*)h->c.q,
-                       (const T*)h->diag, (const T*)h->cx, (const T*)h->cy, (const T*)h->cz, L, h->Ny, h->Nz, e,
+                       (const T*)h->diag, (const T*)h->cx, (const T*)h->cy, (const T*)h->cz,
+                       (const T*)(h->asym ? h->cz2 : h->cz), L, h->Ny, h->Nz, e,
                        h->c.part_dq, n_part, h->c.scal, p->dev, par, halo_tag, h->c.tickets + kTicketWords,
                        (int)((2 * j + 1) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 1));
     MFS_LAUNCH_CHECK();

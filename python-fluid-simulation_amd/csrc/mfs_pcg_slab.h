@@ -86,7 +86,8 @@ k_slab_edge_d(const T* __restrict__ r, const T* __restrict__ d_old, T* __restric
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kApplyBlock)
 k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag, const T* __restrict__ cx,
-                  const T* __restrict__ cy, const T* __restrict__ cz, int L, int Ny, int Nz, SlabEdge e,
+                  const T* __restrict__ cy, const T* __restrict__ cz, const T* __restrict__ czm2, int L, int Ny, int Nz,
+                  SlabEdge e,   // czm2: weights of the -z tap (= cz except for the density operator, DensityCGSolver3D.py:184)
                   double* __restrict__ partial_all, int n_before, double* __restrict__ scal, P2pDev pd, int par,
                   unsigned tag, unsigned* ticket, int ar_ring, unsigned ar_tag) {
   if (scal[S_DONE] != 0.0) return;
@@ -120,7 +121,7 @@ k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     stencil_vec<T, VEC>(out + base, vc, vxp, vxm, vload<T, VEC>(v + base + sy), vload<T, VEC>(v + base - sy),
                         vload<T, VEC>(diag + base), vload<T, VEC>(cx + base + sx), vload<T, VEC>(cx + base),
                         vload<T, VEC>(cy + base + sy), vload<T, VEC>(cy + base), vload<T, VEC>(cz + base), zl, zr, czr,
-                        first, last, true, acc, vload<T, VEC>(cz + base));
+                        first, last, true, acc, vload<T, VEC>(czm2 + base));
   }
   if (lost) slab_fail(scal, 2);
   const double tot = block_sum<kApplyBlock>(acc);

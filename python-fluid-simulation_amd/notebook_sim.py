@@ -163,7 +163,8 @@ class SlabNotebookSimulation(NotebookSimulation):
         from mfs.dist import SlabPartition
         g, dev, dist, group = self.GRES, self.device, self.dist, self.group
         self.CGBuf = CGSolverBuffer(g, precision=self._precision, device=dev)            # the density solve's global RHS
-        self.DensitySolver = SlabDensityCGSolver3D(self.CGBuf, g, self.BOUND_MIN, self.BOUND_SIZE, dist, group)
+        self.DensitySolver = SlabDensityCGSolver3D(self.CGBuf, g, self.BOUND_MIN, self.BOUND_SIZE, dist, group,
+                                                   transport=self._transport)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.part = SlabPartition(g[0], self.world, self.rank)
         lg = SlabPressureCGSolver3D.local_gres(g, self.world, self.rank)
@@ -198,6 +199,7 @@ class SlabNotebookSimulation(NotebookSimulation):
 
     def close(self):
         self.PressureSolver.close()
+        self.DensitySolver.close()
 
 
 def add_box(center, size, dx, rng, keep=None):

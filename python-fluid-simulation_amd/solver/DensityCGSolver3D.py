@@ -176,14 +176,15 @@ class DensityCGSolver3D:
 class SlabDensityCGSolver3D(DensityCGSolver3D):
     """`DensityCGSolver3D` on N GPUs with REPLICATED particles (extension; one process per GPU): same constructor
     arguments plus `dist`, same `solve` signature on the GLOBAL arrays.  The CG loop -- all but a few milliseconds of the
-    solve -- runs slab-decomposed along x (`mfs.dist.SlabCG`, collectives per iteration: the operator is the pressure
-    stencil with the asymmetric -z tap, which the window kernels do not carry yet); the particle splat, `fix_volume`,
+    solve -- runs slab-decomposed along x (`mfs.dist.SlabCG`: window transport like the pressure solve, collectives as
+    the fallback; the operator is the pressure stencil with the asymmetric -z tap); the particle splat, `fix_volume`,
     the RHS, the displacement and the particle update run replicated on every rank, exactly as on one GPU.  The splat's
     atomics make the replicas differ in the last bits, so rank 0's RHS is broadcast (one source of truth), and every rank
     receives every rank's owned planes of the solution.  Collective."""
 
-    def __init__(self, buf, gres, bound_min, bound_size, dist, group=None, check_every=32):
+    def __init__(self, buf, gres, bound_min, bound_size, dist, group=None, check_every=32, transport="auto"):
         from mfs.dist import SlabCG, SlabPartition
+        from mfs.p2p import P2PWindow
         super().__init__(buf, gres, bound_min, bound_size, check_every)
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -194,7 +195,24 @@ class SlabDensityCGSolver3D(DensityCGSolver3D):
         dt, device = buf.b.dtype, buf.b.device
         self._lb, self._lx, self._ld, self._lr, self._lq = (torch.zeros(lg, dtype=dt, device=device) for _ in range(5))
         self._engine = PcgEngine(lg, dt, device)          # replaces the full-grid engine
-        self._cg = SlabCG(self._engine, self.part, self._ld, dist, group, force_multi=True)
+        # transport as for the pressure solve: xGMI stores into HIP-IPC windows when the self-test passes, else collectives
+        if transport not in ("auto", "p2p", "rccl"):
+            raise ValueError("transport must be auto, p2p or rccl")
+        self.window = None
+        if transport != "rccl":
+            self.window = P2PWindow(dist, lg[1] * lg[2] * buf.b.element_size(), device, group)
+            if not self.window.ok:
+                why, self.window = self.window.why, None
+                if transport == "p2p":
+                    raise _lib.MfsError(f"peer-to-peer transport unavailable: {why}")
+        self._cg = SlabCG(self._engine, self.part, self._ld, dist, group, window=self.window, force_multi=True)
+        self.transport = self._cg.mode
+
+    def close(self):
+        """release the window (collective, like construction)"""
+        if self.window is not None:
+            self.window.close()
+            self.window = None
 
     def solve(self, rho0, dt, px, pm, pvol, vx, vy, vz, sphi, sv, lphi, lvol, wx=None, wy=None, wz=None, tol=1e-3):
         from mfs.dist import SlabPartition
@@ -220,6 +238,7 @@ class SlabDensityCGSolver3D(DensityCGSolver3D):
             eng.setup_density(lphi[lo:hi], wx[lo:hi + 1], wy[lo:hi], wz[lo:hi])
             eng.bind(self._lb, self._lx, self._ld, self._lr, self._lq)
             ok, self.iterations = self._cg.solve(tol, self.max_iter, self.check_every)
+            self.transport = "p2p" if getattr(self._cg, "_p2p_active", False) else "rccl"
             st = eng.poll()
             self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
             if not ok:

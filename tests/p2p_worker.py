@@ -69,7 +69,7 @@ def density_mode(rank, world, path, out, dtname, dev):
         g = {k: z[k] for k in z.files}
     gres = tuple(int(v) for v in g["gres"])
     buf = CGSolverBuffer(gres, precision={"f64": "fp64", "f32": "fp32"}[dtname], device=dev)
-    s = SlabDensityCGSolver3D(buf, gres, g["bound_min"], g["bound_size"], dist)
+    s = SlabDensityCGSolver3D(buf, gres, g["bound_min"], g["bound_size"], dist, transport=os.environ.get("P2P_TEST_TRANSPORT", "auto"))
     T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
     px = T(g["px"])
     s.solve(float(g["rho0"]), float(g["dt"]), px, T(g["pm"]), float(g["pvol"]), None, None, None, T(g["sphi"]), T(g["sv"]),
@@ -77,7 +77,8 @@ def density_mode(rank, world, path, out, dtname, dev):
     torch.cuda.synchronize()
     c = lambda t: t.cpu().numpy().astype(np.float64)  # noqa: E731
     np.savez(f"{out}.rank{rank}.npz", px=c(px), x=c(s.x), dx=c(s.dx), dy=c(s.dy), dz=c(s.dz), hist=s.history,
-             iters=s.iterations, delta=s.delta, lq=c(s._lq), lr=c(s._lr))
+             iters=s.iterations, delta=s.delta, lq=c(s._lq), lr=c(s._lr), transport=s.transport)
+    s.close()
 
 
 def timestep_mode(rank, world, path, out, dtname, dev):

@@ -118,14 +118,16 @@ def test_density_weights_feed_the_pressure_solve():
     assert ps.iterations > 0 and ps.delta < 1e-6
 
 
-@pytest.mark.parametrize("name,world", [("d3d_a_12", 2), ("d3d_a_12", 3), ("d3d_b_10x12x14_f32", 2)])
-def test_slab_density_solver_matches_reference(name, world, tmp_path):
+@pytest.mark.parametrize("name,world,transport", [("d3d_a_12", 2, "p2p"), ("d3d_a_12", 3, "p2p"), ("d3d_b_10x12x14_f32", 2, "p2p"),
+                                                  ("d3d_a_12", 2, "rccl")])
+def test_slab_density_solver_matches_reference(name, world, transport, tmp_path):
     """SlabDensityCGSolver3D (replicated particles, CG loop slab-decomposed over `world` processes sharing the GPU):
     history, solution, displacements and moved particles against the goldens of the reference's own solve."""
     from test_p2p_gpu import _run_ranks
     g = golden(name)
-    res = _run_ranks(name, world, tmp_path, "f64", P2P_TEST_MODE="density")
+    res = _run_ranks(name, world, tmp_path, "f64", P2P_TEST_MODE="density", P2P_TEST_TRANSPORT=transport)
     for r in res:
+        assert str(r["transport"]) == transport
         h = r["hist"]
         n = min(21, len(h), len(g["history"]))
         np.testing.assert_allclose(h[:n], g["history"][:n], rtol=1e-9)
