@@ -308,6 +308,12 @@ int mfs_vcg3d_phase_apply(mfs_vcg3d* h, mfs_stream stream);
 int mfs_vcg3d_phase_reduce(mfs_vcg3d* h, int which, mfs_stream stream);
 int mfs_vcg3d_phase_update_xr(mfs_vcg3d* h, mfs_stream stream);
 int mfs_vcg3d_phase_update_d(mfs_vcg3d* h, mfs_stream stream);
+/* The same loop with the halo planes and the two dot products moving through a peer-to-peer window (mfs_p2p_*, below /
+ * above): attach a connected window created with plane_bytes = (Ny*Nz + (Ny+1)*Nz + Ny*(Nz+1)) * sizeof(element);
+ * slab_begin / slab_iterate then enqueue whole iterations without any host-side exchange.  Poll as usual.   */
+int mfs_vcg3d_attach_p2p(mfs_vcg3d* h, mfs_p2p* window);
+int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream);
+int mfs_vcg3d_slab_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream);
 
 /* ------------------------------------------------------------------------- */
 /* Density solver, 3D -- reference solver/DensityCGSolver3D.py */

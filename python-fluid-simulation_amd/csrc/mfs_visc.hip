@@ -19,6 +19,7 @@
 //    Algorithmic traffic: 3 (v) + 7 (vol classes) + 3 (out) scalars + 3 mask bytes
 //    per cell, vs 8x-strided reads of two (2N+1)^3 arrays in the reference.
 #include "mfs_cg_core.h"
+#include "mfs_p2p.h"
 
 // workgroup barrier that waits on LDS traffic only: the global prefetch of the next plane stays in flight
 #define MFS_VISC_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -586,6 +587,7 @@ struct mfs_vcg3d {
   int xcd_order;   // 1 / 0: XCD-contiguous tile order on / off; -1 auto
   int split_x;     // 1: the x update rides in the direction-update kernel (default)
   int skip_top_x;  // slab decomposition: the u row at x = Nx-1 belongs to the right neighbour (a ghost here)
+  mfs_p2p* p2p;    // window transport of the slab loop (mfs_vcg3d_attach_p2p); null: the caller moves halos / scalars
 };
 
 static int64_t class_count(const int64_t gres[3], int p) {
@@ -712,6 +714,109 @@ static int vcg_apply(mfs_vcg3d* h, const void* v, void* out, double* partial, bo
                   : vcg_apply_TM<float, false>(h, v, out, partial, done, st, nparts);
   return masked ? vcg_apply_TM<double, true>(h, v, out, partial, done, st, nparts)
                 : vcg_apply_TM<double, false>(h, v, out, partial, done, st, nparts);
+}
+
+// ---- window transport of the slab loop (mfs_p2p.h): the edge planes of the direction vector and the two dot products
+// travel as self-validating granules written by these kernels straight into the neighbours' windows -- no collective
+// call, no host code inside the loop.  A receive buffer holds the three components' planes back to back.
+struct VSlabPlanes {
+  int64_t off[3];        // element offset of component c in the flat vectors
+  int64_t pe[3];         // elements of one plane of component c
+  int L;                 // local cell planes (the u array has L + 1, only planes 0 .. L-1 take part)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_vslab_send(const T* __restrict__ d, VSlabPlanes g, const double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
+  if (scal[S_DONE] != 0.0) return;
+  const int64_t tot = g.pe[0] + g.pe[1] + g.pe[2];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int side = 0; side < 2; ++side) {
+    u64* const dst = pd.send[side][par];       // [0]: left neighbour's high-ghost buffer, [1]: right neighbour's low-ghost
+    if (!dst) continue;
+    const int plane = side == 0 ? 1 : g.L - 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+      const int c = i < g.pe[0] ? 0 : (i < g.pe[0] + g.pe[1] ? 1 : 2);
+      const int64_t e = i - (c == 0 ? 0 : (c == 1 ? g.pe[0] : g.pe[0] + g.pe[1]));
+      vec_t<T, 1> v;
+      v[0] = d[g.off[c] + (int64_t)plane * g.pe[c] + e];
+      gran_store_vec<T, 1>(dst, i, v, tag);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_vslab_recv(T* __restrict__ d, VSlabPlanes g, double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
+  if (scal[S_DONE] != 0.0) return;
+  const int64_t tot = g.pe[0] + g.pe[1] + g.pe[2];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool lost = false;
+  for (int side = 0; side < 2 && !lost; ++side) {
+    if (side == 0 ? pd.rank == 0 : pd.rank == pd.world - 1) continue;
+    const u64* const src = pd.recv[side][par];
+    const int plane = side == 0 ? 0 : g.L - 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+      const int c = i < g.pe[0] ? 0 : (i < g.pe[0] + g.pe[1] ? 1 : 2);
+      const int64_t e = i - (c == 0 ? 0 : (c == 1 ? g.pe[0] : g.pe[0] + g.pe[1]));
+      vec_t<T, 1> v;
+      if (!gran_load_vec<T, 1>(src, i, tag, pd.timeout_ticks, &v)) { lost = true; break; }
+      d[g.off[c] + (int64_t)plane * g.pe[c] + e] = v[0];
+    }
+  }
+  if (lost) slab_fail(scal, 2);
+}
+
+// ONE wave: scal[slot] (this rank's sum, from k_reduce) -> every rank's window -> the world's total in rank order
+static __global__ void __launch_bounds__(kWave)
+k_vslab_allreduce(double* __restrict__ scal, int slot, int check_done, P2pDev pd, int ring, unsigned tag) {
+  if (check_done && scal[S_DONE] != 0.0) return;
+  bool ok;
+  const double tot = slab_allreduce_wave(pd, ring, tag, scal[slot], &ok);
+  if (threadIdx.x != 0) return;
+  if (!ok) { slab_fail(scal, 1); return; }
+  scal[slot] = tot;
+}
+
+static VSlabPlanes vslab_planes(const mfs_vcg3d* h) {
+  VSlabPlanes g;
+  for (int c = 0; c < 3; ++c) { g.off[c] = h->off[c]; g.pe[c] = (int64_t)h->g.sh(c, 1) * h->g.sh(c, 2); }
+  g.L = h->g.N[0];
+  return g;
+}
+static unsigned vslab_tag(const mfs_p2p* p, int64_t episode) {
+  return 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)(episode & 0xfffff);
+}
+static int vslab_allreduce(mfs_vcg3d* h, int slot, int check_done, int64_t episode, hipStream_t st) {
+  hipLaunchKernelGGL(k_vslab_allreduce, dim3(1), dim3(kWave), 0, st, h->c.scal, slot, check_done, h->p2p->dev,
+                     (int)(episode & (kArRing - 1)), vslab_tag(h->p2p, episode));
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+template <typename T>
+static int vslab_iteration(mfs_vcg3d* h, hipStream_t st) {
+  mfs_p2p* p = h->p2p;
+  const int64_t j = h->c.iter_enq;
+  const int par = (int)(j & 1);
+  const VSlabPlanes g = vslab_planes(h);
+  const unsigned halo_tag = vslab_tag(p, j + 1);
+  const int64_t tot = g.pe[0] + g.pe[1] + g.pe[2];
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(512, (tot + 255) / 256));
+  int e, np = 0;
+  if (p->world > 1 && g.L >= 3) {   // d's edge planes into the neighbours' windows, the ghosts out of the own one
+    hipLaunchKernelGGL((k_vslab_send<T>), dim3(grid), dim3(256), 0, st, (const T*)h->c.d, g, h->c.scal, p->dev, par, halo_tag);
+    hipLaunchKernelGGL((k_vslab_recv<T>), dim3(grid), dim3(256), 0, st, (T*)h->c.d, g, h->c.scal, p->dev, par, halo_tag);
+    MFS_LAUNCH_CHECK();
+  }
+  if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;
+  h->c.n_part_dq = np;
+  if ((e = core_reduce(h->c, 0, 1, st))) return e;
+  if ((e = vslab_allreduce(h, S_DQ, 1, 2 * j + 1, st))) return e;
+  if ((e = core_update_xr(h->c, false, st))) return e;
+  if ((e = core_reduce(h->c, 1, 1, st))) return e;
+  if ((e = vslab_allreduce(h, S_RR, 1, 2 * j + 2, st))) return e;
+  return core_update_d(h->c, false, st);
 }
 
 extern "C" {
@@ -910,6 +1015,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->xcd_order = env_int("MFS_VISC_XCD", -1);
   h->split_x = env_int("MFS_VISC_SPLIT_X", 1);
   h->skip_top_x = 0;
+  h->p2p = nullptr;
   h->xchunk_tiled = std::max(1, env_int("MFS_VISC_XCHUNK", 32));
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
@@ -1024,6 +1130,37 @@ int mfs_vcg3d_phase_update_xr(mfs_vcg3d* h, mfs_stream stream) {
 int mfs_vcg3d_phase_update_d(mfs_vcg3d* h, mfs_stream stream) {
   MFS_REQUIRE(h, "null handle");
   return core_update_d(h->c, false, (hipStream_t)stream);
+}
+
+// window transport for the slab loop: `p` must have been created with plane_bytes = the three edge planes of this
+// engine's vectors, (Ny*Nz + (Ny+1)*Nz + Ny*(Nz+1)) * sizeof(element); null detaches
+int mfs_vcg3d_attach_p2p(mfs_vcg3d* h, mfs_p2p* p) {
+  MFS_REQUIRE(h, "null handle");
+  if (p) {
+    MFS_REQUIRE(p->connected, "mfs_p2p_connect has not been called");
+    const VSlabPlanes g = vslab_planes(h);
+    MFS_REQUIRE((size_t)(g.pe[0] + g.pe[1] + g.pe[2]) * h->c.elt == p->plane_bytes,
+                "window plane size != the three edge planes of this engine");
+  }
+  h->p2p = p;
+  return MFS_OK;
+}
+
+int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup && h->p2p, "engine not bound / set up / no window attached");
+  ++h->p2p->epoch;
+  if (int e = mfs_vcg3d_begin_local(h, tol, stream)) return e;
+  if (int e = vslab_allreduce(h, S_RR, 0, 0, (hipStream_t)stream)) return e;
+  return core_begin_finish(h->c, (hipStream_t)stream);
+}
+
+int mfs_vcg3d_slab_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
+  MFS_REQUIRE(h && h->c.x && h->is_setup && h->p2p, "engine not bound / set up / no window attached");
+  for (int64_t i = 0; i < n; ++i) {
+    const int e = h->dt == MFS_F32 ? vslab_iteration<float>(h, (hipStream_t)stream) : vslab_iteration<double>(h, (hipStream_t)stream);
+    if (e) return e;
+  }
+  return MFS_OK;
 }
 
 int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {

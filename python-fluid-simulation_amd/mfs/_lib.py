@@ -115,6 +115,9 @@ SIGNATURES = {
     "mfs_vcg3d_phase_reduce": (_i, [_p, _i, _p]),
     "mfs_vcg3d_phase_update_xr": (_i, [_p, _p]),
     "mfs_vcg3d_phase_update_d": (_i, [_p, _p]),
+    "mfs_vcg3d_attach_p2p": (_i, [_p, _p]),
+    "mfs_vcg3d_slab_begin": (_i, [_p, _d, _p]),
+    "mfs_vcg3d_slab_iterate": (_i, [_p, _i64, _p]),
     "mfs_visc_valid3d": (_i, [_pi64, _i, _p, _i, _p, _p]),
     "mfs_visc_extrapolate_sweep3d": (_i, [_pi64, _i, _p, _p, _i, _p, _p, _p]),
     "mfs_grid_extrapolate3d": (_i, [_pi64, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),

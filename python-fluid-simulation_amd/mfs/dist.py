@@ -262,7 +262,7 @@ class SlabVCG:
     `ops`: mfs.vcg.VcgEngine (or a stand-in with the same phase interface); `d_views`: the three component
     views of the bound direction vector."""
 
-    def __init__(self, ops, part, d_views, dist=None, group=None):
+    def __init__(self, ops, part, d_views, dist=None, group=None, window=None):
         self.ops, self.part, self.dist, self.group = ops, part, dist, group
         self.d_views = list(d_views)
         self.L = int(self.d_views[1].shape[0])
@@ -270,6 +270,16 @@ class SlabVCG:
             raise ValueError("d views do not match the partition's local plane count")
         self.multi = dist is not None and part.world > 1
         ops.set_slab(part.right is not None)
+        # window: a connected, self-tested mfs.p2p.P2PWindow of ops.edge_plane_bytes() -> the halo planes and the two
+        # dot products of the CG loop move as xGMI stores from kernels of the library (mfs_vcg3d_slab_*); the
+        # collectives below remain for the extrapolation sweeps and as the fallback
+        self.window = window if (window is not None and window.ok) else None
+        if self.window is not None:
+            ops.attach_p2p(self.window)
+
+    @property
+    def mode(self):
+        return "p2p" if self.window is not None else ("rccl" if self.multi else "single")
 
     def _allreduce(self, slot):
         if self.multi:
@@ -279,12 +289,18 @@ class SlabVCG:
         exchange_edge_planes(self.dist if self.multi else None, self.group, self.part, list(fields), self.L)
 
     def begin(self, tol):
+        if self.window is not None:
+            self.ops.slab_begin(tol)
+            return
         self.ops.begin_local(tol)              # q = A x on the local slab (x's ghosts are the caller's), d = r = b - q
         self._allreduce(_lib.S_RR)
         self.ops.begin_finish()
 
     def iterate(self, n):
         ops = self.ops
+        if self.window is not None:
+            ops.slab_iterate(n)
+            return
         for _ in range(int(n)):
             self.exchange(self.d_views)
             ops.phase_apply()

@@ -102,6 +102,21 @@ class VcgEngine:
     def phase_update_d(self):
         _lib.check(self.lib.mfs_vcg3d_phase_update_d(self.h, T.stream()), "mfs_vcg3d_phase_update_d")
 
+    # ---- the same loop over a peer-to-peer window (mfs/p2p.py): no host-side exchange inside the loop
+    def edge_plane_bytes(self):
+        """bytes of the three edge planes one neighbour receives per iteration (the window's plane size)"""
+        return sum(int(np.prod(shp[1:])) for shp in self.face_shapes) * torch.empty(0, dtype=self.dtype).element_size()
+
+    def attach_p2p(self, window):
+        self._window = window            # keep it alive as long as the engine may use it
+        _lib.check(self.lib.mfs_vcg3d_attach_p2p(self.h, window.h if window is not None else None), "mfs_vcg3d_attach_p2p")
+
+    def slab_begin(self, tol):
+        _lib.check(self.lib.mfs_vcg3d_slab_begin(self.h, float(tol), T.stream()), "mfs_vcg3d_slab_begin")
+
+    def slab_iterate(self, n):
+        _lib.check(self.lib.mfs_vcg3d_slab_iterate(self.h, int(n), T.stream()), "mfs_vcg3d_slab_iterate")
+
     def poll(self):
         it, done = C.c_int64(), C.c_int()
         delta, alpha, beta = C.c_double(), C.c_double(), C.c_double()

@@ -170,7 +170,8 @@ class SlabNotebookSimulation(NotebookSimulation):
         lg = SlabPressureCGSolver3D.local_gres(g, self.world, self.rank)
         self._slab_buf = CGSolverBuffer(lg, precision=self._precision, device=dev)
         self.PressureSolver = SlabPressureCGSolver3D(self._slab_buf, g, self.GDX, dist, group, transport=self._transport)
-        self.ViscositySolver = SlabViscosityCGSolver3D(g, self.BOUND_SIZE, dist, group, precision=self._precision, device=dev)
+        self.ViscositySolver = SlabViscosityCGSolver3D(g, self.BOUND_SIZE, dist, group, precision=self._precision, device=dev,
+                                                       transport=self._transport)
 
     def _solve_grid(self, dt, tick, t):
         from mfs.dist import SlabPartition
@@ -200,6 +201,7 @@ class SlabNotebookSimulation(NotebookSimulation):
     def close(self):
         self.PressureSolver.close()
         self.DensitySolver.close()
+        self.ViscositySolver.close()
 
 
 def add_box(center, size, dx, rng, keep=None):

@@ -165,8 +165,9 @@ class SlabViscosityCGSolver3D(ViscosityCGSolver3D):
     semantics on the global problem: same extrapolation, RHS and CG iterates (up to the summation order of the two
     dot products across ranks), `ValueError("Failed to converge!")` after prod(global gres) iterations, velocities
     written in place on the local planes (the ghost planes receive the neighbours' values).  Collective: every
-    rank calls `solve` in step.  Transport: torch.distributed (RCCL on the GPUs): per iteration one batched halo
-    exchange of the direction vector's edge planes and two scalar all-reduces (mfs.dist.SlabVCG)."""
+    rank calls `solve` in step.  Per iteration the edge planes of the direction vector (three components) and two dot
+    products cross ranks: as xGMI stores from the library's kernels into HIP-IPC windows ("p2p", default when the
+    window self-test passes) or as torch.distributed collectives (RCCL; "rccl") -- mfs.dist.SlabVCG."""
 
     @staticmethod
     def local_gres(gres, world, rank):
@@ -174,8 +175,9 @@ class SlabViscosityCGSolver3D(ViscosityCGSolver3D):
         g = T.as_gres(gres)
         return (SlabPartition(g[0], world, rank).local_planes, g[1], g[2])
 
-    def __init__(self, gres, bound_size, dist, group=None, precision=None, device=None, check_every=32):
+    def __init__(self, gres, bound_size, dist, group=None, precision=None, device=None, check_every=32, transport="auto"):
         from mfs.dist import SlabPartition, SlabVCG
+        from mfs.p2p import P2PWindow
         gg = T.as_gres(gres)
         self.global_gres = gg
         self.dist, self.group = dist, group
@@ -186,7 +188,25 @@ class SlabViscosityCGSolver3D(ViscosityCGSolver3D):
         self.cell_size = np.array(T.as_f64_list(bound_size, 3)) / np.array(gg, dtype=np.float64)
         self.cell_vol = float(np.prod(self.cell_size))
         self.max_iter = int(np.prod(gg))
-        self._cg = SlabVCG(self._engine, self.part, (self.d_x, self.d_y, self.d_z), dist, group)
+        # transport of the CG loop: "p2p" = xGMI stores into HIP-IPC windows (mfs/p2p.py), "rccl" = torch.distributed
+        # collectives per iteration, "auto" = p2p when its self-test passes on every rank
+        if transport not in ("auto", "p2p", "rccl"):
+            raise ValueError("transport must be auto, p2p or rccl")
+        self.window = None
+        if transport != "rccl":
+            self.window = P2PWindow(dist, self._engine.edge_plane_bytes(), self.vol.device, group)
+            if not self.window.ok:
+                why, self.window = self.window.why, None
+                if transport == "p2p":
+                    raise _lib.MfsError(f"peer-to-peer transport unavailable: {why}")
+        self._cg = SlabVCG(self._engine, self.part, (self.d_x, self.d_y, self.d_z), dist, group, window=self.window)
+        self.transport = self._cg.mode
+
+    def close(self):
+        """release the window (collective, like construction)"""
+        if self.window is not None:
+            self.window.close()
+            self.window = None
 
     def solve(self, dt, mu, rho, vx, vy, vz, sphi, sv, lphi, lvol, tol=1e-3):
         g = self._g

@@ -47,7 +47,8 @@ def viscosity_mode(rank, world, path, out, dtname, dev):
     with np.load(path, allow_pickle=False) as z:
         g = {k: z[k] for k in z.files}
     gres = tuple(int(v) for v in g["gres"])
-    s = SlabViscosityCGSolver3D(gres, g["bound_size"], dist, precision={"f64": "fp64", "f32": "fp32"}[dtname], device=dev)
+    s = SlabViscosityCGSolver3D(gres, g["bound_size"], dist, precision={"f64": "fp64", "f32": "fp32"}[dtname], device=dev,
+                                transport=os.environ.get("P2P_TEST_TRANSPORT", "auto"))
     lo, hi = s.part.local_range
     T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
     vx, vy, vz = T(g["in_vx"][lo:hi + 1]), T(g["in_vy"][lo:hi]), T(g["in_vz"][lo:hi])
@@ -58,7 +59,8 @@ def viscosity_mode(rank, world, path, out, dtname, dev):
     np.savez(f"{out}.rank{rank}.npz", vx=vx.cpu().numpy(), vy=vy.cpu().numpy(), vz=vz.cpu().numpy(),
              x_x=c(s.x_x), x_y=c(s.x_y), x_z=c(s.x_z), b_x=c(s.b_x), b_y=c(s.b_y), b_z=c(s.b_z),
              q_x=c(s.q_x), r_x=c(s.r_x), q_y=c(s.q_y), r_y=c(s.r_y),
-             hist=s.history, iters=s.iterations, lo=lo, hi=hi)
+             hist=s.history, iters=s.iterations, lo=lo, hi=hi, transport=s.transport)
+    s.close()
 
 
 def density_mode(rank, world, path, out, dtname, dev):

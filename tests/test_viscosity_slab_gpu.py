@@ -1,6 +1,6 @@
 """Slab-decomposed viscosity solve (solver.ViscosityCGSolver3D.SlabViscosityCGSolver3D, mfs/dist.py:SlabVCG) on ONE
-MI355X: 1, 2 and 3 ranks -- separate processes sharing the card, collectives over gloo (RCCL on a node) -- each
-solving its x-slab of a golden scene.  The assembled RHS, solution and written-back velocities are compared with
+MI355X: 1, 2 and 3 ranks -- separate processes sharing the card; halo planes and dot products through HIP-IPC
+windows ("p2p") or collectives over gloo ("rccl"; RCCL on a node) -- each solving its x-slab of a golden scene.  The assembled RHS, solution and written-back velocities are compared with
 the golden outputs of the reference's own `solve` on the whole grid, and the residual history with the golden one."""
 import numpy as np
 import pytest
@@ -32,13 +32,15 @@ def _assemble(g, res):
     return out
 
 
-@pytest.mark.parametrize("name,world,dtname", [
-    ("v3d_a_12", 1, "f64"), ("v3d_a_12", 2, "f64"), ("v3d_b_10x12x14", 2, "f64"), ("v3d_b_10x12x14", 3, "f64"),
-    ("v3d_a_12", 3, "f32"), ("v3d_c_16_mu50", 2, "f64"),
+@pytest.mark.parametrize("name,world,dtname,transport", [
+    ("v3d_a_12", 1, "f64", "p2p"), ("v3d_a_12", 2, "f64", "p2p"), ("v3d_b_10x12x14", 2, "f64", "p2p"),
+    ("v3d_b_10x12x14", 3, "f64", "p2p"), ("v3d_a_12", 3, "f32", "p2p"), ("v3d_c_16_mu50", 2, "f64", "p2p"),
+    ("v3d_a_12", 2, "f64", "rccl"), ("v3d_b_10x12x14", 3, "f64", "rccl"), ("v3d_a_12", 3, "f32", "rccl"),
 ])
-def test_slab_viscosity_matches_reference_outputs(name, world, dtname, tmp_path):
+def test_slab_viscosity_matches_reference_outputs(name, world, dtname, transport, tmp_path):
     g = golden(name)
-    res = _run_ranks(name, world, tmp_path, dtname, P2P_TEST_MODE="viscosity")
+    res = _run_ranks(name, world, tmp_path, dtname, P2P_TEST_MODE="viscosity", P2P_TEST_TRANSPORT=transport)
+    assert all(str(r["transport"]) == transport for r in res)
     a = _assemble(g, res)
     for r in res:          # ghost planes of q and r stay exactly 0: the local dot products count owned faces only
         L = int(r["hi"]) - int(r["lo"])

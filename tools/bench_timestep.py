@@ -59,7 +59,7 @@ if dist is not None:
 if rank == 0:
   print(json.dumps({"workload": f"notebook time step {N}^3, {sim.particle.num_particles} particles, mu={mu}",
                   "ranks": world, "decomposition": "single GPU" if dist is None else
-                  f"viscosity + pressure CG on x-slabs x{world} ({sim.PressureSolver.transport}), other stages replicated"
+                  f"density, viscosity and pressure CG loops on x-slabs x{world} (transports {sim.DensitySolver.transport}/{sim.ViscositySolver.transport}/{sim.PressureSolver.transport}), particle stages replicated"
                   + (" [REHEARSAL: ranks share one GPU]" if shared else ""),
                   "state_precision": os.environ.get("MFS_PRECISION", "fp64"), "steps": steps,
                   "s_per_step": round(t_all / steps, 4), "setup_s": round(t_setup, 2),
