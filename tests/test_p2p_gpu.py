@@ -108,7 +108,8 @@ def test_slab_p2p_deferred_x_update(name, world, tmp_path):
     gres = tuple(int(v) for v in g["gres"])
     out = {}
     for defer in ("0", "1"):
-        res = _run_ranks(name, world, tmp_path, "f64", MFS_DEFER_X=defer)
+        # the deferred form also with the edge-plane sends on the second stream (its default on production-size planes)
+        res = _run_ranks(name, world, tmp_path, "f64", MFS_DEFER_X=defer, MFS_SLAB_AUX_STREAM=defer)
         x = np.zeros(gres)
         for r in res:
             lo, hi = int(r["lo"]), int(r["hi"])
