@@ -725,54 +725,55 @@ struct VSlabPlanes {
   int L;                 // local cell planes (the u array has L + 1, only planes 0 .. L-1 take part)
 };
 
+// One launch moves both directions: blocks [0, nsend) store this rank's two edge planes (all three components) into the
+// neighbours' receive buffers, the remaining blocks unpack the own window into the ghost planes, re-reading any granule
+// that does not carry this iteration's tag yet.  The senders never wait, and they are the lower-numbered blocks
+// (dispatched first), so the waiting blocks cannot starve them.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_vslab_send(const T* __restrict__ d, VSlabPlanes g, const double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
+k_vslab_exchange(T* __restrict__ d, VSlabPlanes g, double* __restrict__ scal, P2pDev pd, int par, unsigned tag, int nsend) {
   if (scal[S_DONE] != 0.0) return;
   const int64_t tot = g.pe[0] + g.pe[1] + g.pe[2];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int side = 0; side < 2; ++side) {
-    u64* const dst = pd.send[side][par];       // [0]: left neighbour's high-ghost buffer, [1]: right neighbour's low-ghost
-    if (!dst) continue;
-    const int plane = side == 0 ? 1 : g.L - 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
-      const int c = i < g.pe[0] ? 0 : (i < g.pe[0] + g.pe[1] ? 1 : 2);
-      const int64_t e = i - (c == 0 ? 0 : (c == 1 ? g.pe[0] : g.pe[0] + g.pe[1]));
-      vec_t<T, 1> v;
-      v[0] = d[g.off[c] + (int64_t)plane * g.pe[c] + e];
-      gran_store_vec<T, 1>(dst, i, v, tag);
-    }
-  }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_vslab_recv(T* __restrict__ d, VSlabPlanes g, double* __restrict__ scal, P2pDev pd, int par, unsigned tag) {
-  if (scal[S_DONE] != 0.0) return;
-  const int64_t tot = g.pe[0] + g.pe[1] + g.pe[2];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool sender = (int)blockIdx.x < nsend;
+  const int nblk = sender ? nsend : (int)gridDim.x - nsend, blk = sender ? (int)blockIdx.x : (int)blockIdx.x - nsend;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
   bool lost = false;
   for (int side = 0; side < 2 && !lost; ++side) {
-    if (side == 0 ? pd.rank == 0 : pd.rank == pd.world - 1) continue;
+    u64* const dst = pd.send[side][par];       // [0]: left neighbour's high-ghost buffer, [1]: right neighbour's low-ghost
     const u64* const src = pd.recv[side][par];
-    const int plane = side == 0 ? 0 : g.L - 1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+    if (sender ? dst == nullptr : (side == 0 ? pd.rank == 0 : pd.rank == pd.world - 1)) continue;
+    const int plane = sender ? (side == 0 ? 1 : g.L - 2) : (side == 0 ? 0 : g.L - 1);
+    for (int64_t i = (int64_t)blk * blockDim.x + threadIdx.x; i < tot; i += stride) {
       const int c = i < g.pe[0] ? 0 : (i < g.pe[0] + g.pe[1] ? 1 : 2);
       const int64_t e = i - (c == 0 ? 0 : (c == 1 ? g.pe[0] : g.pe[0] + g.pe[1]));
+      T* const cell = d + g.off[c] + (int64_t)plane * g.pe[c] + e;
       vec_t<T, 1> v;
-      if (!gran_load_vec<T, 1>(src, i, tag, pd.timeout_ticks, &v)) { lost = true; break; }
-      d[g.off[c] + (int64_t)plane * g.pe[c] + e] = v[0];
+      if (sender) {
+        v[0] = *cell;
+        gran_store_vec<T, 1>(dst, i, v, tag);
+      } else {
+        if (!gran_load_vec<T, 1>(src, i, tag, pd.timeout_ticks, &v)) { lost = true; break; }
+        *cell = v[0];
+      }
     }
   }
   if (lost) slab_fail(scal, 2);
 }
 
-// ONE wave: scal[slot] (this rank's sum, from k_reduce) -> every rank's window -> the world's total in rank order
-static __global__ void __launch_bounds__(kWave)
-k_vslab_allreduce(double* __restrict__ scal, int slot, int check_done, P2pDev pd, int ring, unsigned tag) {
+// ONE block: this rank's partial sums (k_reduce's order) -> every rank's window -> the world's total in rank order -> scal[slot]
+static __global__ void __launch_bounds__(kBlock)
+k_vslab_allreduce(const double* __restrict__ partial, int count, double* __restrict__ scal, int slot, int check_done, P2pDev pd,
+                  int ring, unsigned tag) {
   if (check_done && scal[S_DONE] != 0.0) return;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) acc += partial[i];
+  const double loc = block_sum<kBlock>(acc);          // thread 0
+  __shared__ double s_loc;
+  if (threadIdx.x == 0) s_loc = loc;
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
   bool ok;
-  const double tot = slab_allreduce_wave(pd, ring, tag, scal[slot], &ok);
+  const double tot = slab_allreduce_wave(pd, ring, tag, s_loc, &ok);
   if (threadIdx.x != 0) return;
   if (!ok) { slab_fail(scal, 1); return; }
   scal[slot] = tot;
@@ -788,7 +789,9 @@ static unsigned vslab_tag(const mfs_p2p* p, int64_t episode) {
   return 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)(episode & 0xfffff);
 }
 static int vslab_allreduce(mfs_vcg3d* h, int slot, int check_done, int64_t episode, hipStream_t st) {
-  hipLaunchKernelGGL(k_vslab_allreduce, dim3(1), dim3(kWave), 0, st, h->c.scal, slot, check_done, h->p2p->dev,
+  const double* part = slot == S_DQ ? h->c.part_dq : h->c.part_rr;
+  const int count = slot == S_DQ ? h->c.n_part_dq : h->c.n_part_rr;
+  hipLaunchKernelGGL(k_vslab_allreduce, dim3(1), dim3(kBlock), 0, st, part, count, h->c.scal, slot, check_done, h->p2p->dev,
                      (int)(episode & (kArRing - 1)), vslab_tag(h->p2p, episode));
   MFS_LAUNCH_CHECK();
   return MFS_OK;
@@ -802,20 +805,18 @@ static int vslab_iteration(mfs_vcg3d* h, hipStream_t st) {
   const VSlabPlanes g = vslab_planes(h);
   const unsigned halo_tag = vslab_tag(p, j + 1);
   const int64_t tot = g.pe[0] + g.pe[1] + g.pe[2];
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(512, (tot + 255) / 256));
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(256, (tot + 255) / 256));
   int e, np = 0;
   if (p->world > 1 && g.L >= 3) {   // d's edge planes into the neighbours' windows, the ghosts out of the own one
-    hipLaunchKernelGGL((k_vslab_send<T>), dim3(grid), dim3(256), 0, st, (const T*)h->c.d, g, h->c.scal, p->dev, par, halo_tag);
-    hipLaunchKernelGGL((k_vslab_recv<T>), dim3(grid), dim3(256), 0, st, (T*)h->c.d, g, h->c.scal, p->dev, par, halo_tag);
+    hipLaunchKernelGGL((k_vslab_exchange<T>), dim3(2 * grid), dim3(256), 0, st, (T*)h->c.d, g, h->c.scal, p->dev, par, halo_tag,
+                       grid);
     MFS_LAUNCH_CHECK();
   }
   if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;
   h->c.n_part_dq = np;
-  if ((e = core_reduce(h->c, 0, 1, st))) return e;
-  if ((e = vslab_allreduce(h, S_DQ, 1, 2 * j + 1, st))) return e;
+  if ((e = vslab_allreduce(h, S_DQ, 1, 2 * j + 1, st))) return e;     // local partials -> d.q over all ranks
   if ((e = core_update_xr(h->c, false, st))) return e;
-  if ((e = core_reduce(h->c, 1, 1, st))) return e;
-  if ((e = vslab_allreduce(h, S_RR, 1, 2 * j + 2, st))) return e;
+  if ((e = vslab_allreduce(h, S_RR, 1, 2 * j + 2, st))) return e;     // r.r over all ranks
   return core_update_d(h->c, false, st);
 }
 
@@ -1149,9 +1150,13 @@ int mfs_vcg3d_attach_p2p(mfs_vcg3d* h, mfs_p2p* p) {
 int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup && h->p2p, "engine not bound / set up / no window attached");
   ++h->p2p->epoch;
-  if (int e = mfs_vcg3d_begin_local(h, tol, stream)) return e;
-  if (int e = vslab_allreduce(h, S_RR, 0, 0, (hipStream_t)stream)) return e;
-  return core_begin_finish(h->c, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = core_begin_pre(h->c, tol, false, st)) return e;
+  int np = 0;
+  if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
+  if (int e = core_begin_post(h->c, st, false)) return e;        // d = r = b - q, partials of r.r
+  if (int e = vslab_allreduce(h, S_RR, 0, 0, st)) return e;
+  return core_begin_finish(h->c, st);
 }
 
 int mfs_vcg3d_slab_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
