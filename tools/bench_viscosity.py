@@ -34,10 +34,25 @@ from mfs.dist import SlabPartition, SlabVCG
 cgs = SlabVCG(eng, SlabPartition(N, 1, 0), (s.d_x, s.d_y, s.d_z))
 cgs.begin(0.0); cgs.iterate(10); torch.cuda.synchronize()
 t0 = time.perf_counter(); cgs.iterate(iters); torch.cuda.synchronize(); t_slab = (time.perf_counter() - t0) / iters
+# ... and the same loop as the library enqueues it over a peer-to-peer window (1-rank window: the all-reduces go through
+# the window to this rank itself, no planes move): what the multi-GPU window loop costs before xGMI
+import torch.distributed as dist
+from mfs.p2p import P2PWindow
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+dist.init_process_group("gloo", rank=0, world_size=1)
+win = P2PWindow(dist, eng.edge_plane_bytes(), dev)
+t_win = float("nan")
+if win.ok:
+    cgw = SlabVCG(eng, SlabPartition(N, 1, 0), (s.d_x, s.d_y, s.d_z), dist, window=win)
+    cgw.begin(0.0); cgw.iterate(10); torch.cuda.synchronize()
+    t0 = time.perf_counter(); cgw.iterate(iters); torch.cuda.synchronize(); t_win = (time.perf_counter() - t0) / iters
+    eng.attach_p2p(None)
+    win.close()
+dist.destroy_process_group()
 cells = N ** 3
 out = {"workload": f"ViscosityCGSolver3D {N}^3 {dts}", "solve_iterations": s.iterations, "solve_s": round(t_solve, 4),
        "iter_us": round(t_it * 1e6, 2), "iters_per_s": round(1 / t_it, 1), "Mcells_per_s": round(cells / t_it / 1e6, 1),
        "iter_GBs_alg(43N^3)": round(43 * cells * esz / t_it / 1e9, 1),
-       "slab_phase_loop_iter_us": round(t_slab * 1e6, 2),
+       "slab_phase_loop_iter_us": round(t_slab * 1e6, 2), "slab_window_loop_iter_us": round(t_win * 1e6, 2),
        "apply_us": round(t_ap * 1e6, 2), "apply_GBs_alg(16N^3)": round(16 * cells * esz / t_ap / 1e9, 1)}
 print(json.dumps(out))
