@@ -442,6 +442,51 @@ k_vcg_apply_fused(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// The fused box AND the three boundary slabs in one launch (one kernel boundary less per CG iteration -- what counts on
+// launch-bound grids): blocks [0, gmain) are k_vcg_apply_fused's, the rest k_vcg_apply_slabs'; same block -> partial-sum
+// slot mapping as the two launches, so the dot product is bit-identical.
+template <typename T, bool MASK>
+__global__ void __launch_bounds__(256)
+k_vcg_apply_all(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
+                int xchunk, int nbz, int nby, int xcd_order, int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1,
+                double* __restrict__ partial, const double* __restrict__ done_flag) {
+  if (done_flag && *done_flag != 0.0) return;
+  double acc = 0.0;
+  if ((int)blockIdx.x < gmain) {
+    const int Nx = c.N[0], Ny = c.N[1], Nz = c.N[2];
+    int lb = blockIdx.x;
+    if (xcd_order) {                                         // xcd_logical_block over the first gmain blocks
+      const int nch = min(gmain, 8), xcd = lb % nch, slot = lb / nch, per = gmain / nch, extra = gmain - per * nch;
+      lb = xcd * per + min(xcd, extra) + slot;
+    }
+    const int bz = lb % nbz, by = (lb / nbz) % nby, bxk = lb / (nbz * nby);
+    const int zr = 1 + bz * 64 + (threadIdx.x & 63), yr = 1 + by * 4 + (threadIdx.x >> 6);
+    const bool active = zr <= Nz - 2 && yr <= Ny - 2;
+    const int z = min(zr, Nz - 2), y = min(yr, Ny - 2);
+    const int x0 = 1 + bxk * xchunk, x1 = min(x0 + xchunk, Nx - 1);
+    for (int x = x0; x < x1; ++x) {
+      double o0, o1, o2;
+      const double r0 = vcg_row<T, 0, MASK>(c, k1, k2, v, x, y, z, o0);
+      const double r1 = vcg_row<T, 1, MASK>(c, k1, k2, v, x, y, z, o1);
+      const double r2 = vcg_row<T, 2, MASK>(c, k1, k2, v, x, y, z, o2);
+      if (active) {
+        const T t0 = (T)r0, t1 = (T)r1, t2 = (T)r2;
+        ox[((int64_t)x * Ny + y) * Nz + z] = t0;
+        oy[((int64_t)x * (Ny + 1) + y) * Nz + z] = t1;
+        oz[((int64_t)x * Ny + y) * (Nz + 1) + z] = t2;
+        acc += o0 * (double)t0 + o1 * (double)t1 + o2 * (double)t2;
+      }
+    }
+  } else {
+    const int b = (int)blockIdx.x - gmain, g2 = (int)gridDim.x - gmain - g0 - g1;
+    if (b < g0) acc = vcg_slab_rows<T, 0, MASK>(c, k1, k2, v, ox, b0, b, g0);
+    else if (b < g0 + g1) acc = vcg_slab_rows<T, 1, MASK>(c, k1, k2, v, oy, b1, b - g0, g1);
+    else acc = vcg_slab_rows<T, 2, MASK>(c, k1, k2, v, oz, b2, b - g0 - g1, g2);
+  }
+  const double tot = block_sum<256>(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
 // The per-iteration kernel, LDS-staged: a workgroup owns a TY x TZ tile of cells and marches over a
 // chunk of x planes.  The ten operand arrays of the operator (3 velocity components, 7 volume classes)
 // are staged plane by plane into LDS as (TY+2) x (TZ+2) tiles -- one ring of three planes (x-1, x, x+1)
@@ -587,6 +632,7 @@ struct mfs_vcg3d {
   int xcd_order;   // 1 / 0: XCD-contiguous tile order on / off; -1 auto
   int split_x;     // 1: the x update rides in the direction-update kernel (default)
   int skip_top_x;  // slab decomposition: the u row at x = Nx-1 belongs to the right neighbour (a ghost here)
+  int merge_slabs; // 1 / 0: the fused box and the boundary slabs in one launch (default) / two
   mfs_p2p* p2p;    // window transport of the slab loop (mfs_vcg3d_attach_p2p); null: the caller moves halos / scalars
 };
 
@@ -627,6 +673,19 @@ static int launch_rows_direct(const int64_t gres[3], double scale, double mu, co
   return MFS_OK;
 }
 
+// the three slabs of interior faces outside the fused box: u at x = Nx-1, v at y = Ny-1, w at z = Nz-1
+static Box3 vslab_box(const mfs_vcg3d* h, int ax) {
+  Box3 b;
+  for (int a = 0; a < 3; ++a) { b.lo[a] = 1; b.hi[a] = h->g.sh(ax, a) - 1; }
+  b.lo[ax] = h->g.N[ax] - 1;
+  b.hi[ax] = h->g.N[ax];
+  return b;
+}
+static int vslab_grid(const Box3& b) {
+  const int64_t n = (int64_t)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(256, (n + 255) / 256));
+}
+
 template <typename T, bool MASK>
 static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial, const double* done, hipStream_t st,
                         int* nparts) {
@@ -658,6 +717,19 @@ static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial,
                          h->k1, h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], xc, tbz, nby, xcd, partial + used,
                          done);
       used += tgrid;
+    } else if (h->merge_slabs != 0) {
+      // in-process A/B (tools/visc_ab.py), us per iteration, two launches -> one: 64^3 fp64 35.0 -> 28.0, 128^3 fp32
+      // 70.7 -> 67.4, 192^3 244.8 -> 250.0, 256^3 681 -> 672 (run-to-run and box-to-box spread at 256^3: 618 .. 685)
+      // one launch for the box and the three boundary slabs (below): same partial slots as the two launches
+      const Box3 b0 = vslab_box(h, 0), b1 = vslab_box(h, 1), b2 = vslab_box(h, 2);
+      const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
+      hipLaunchKernelGGL((k_vcg_apply_all<T, MASK>), dim3(grid + g0 + g1 + g2), dim3(256), 0, st, h->cp, h->k1, h->k2, vv,
+                         ob + h->off[0], ob + h->off[1], ob + h->off[2], xchunk, nbz, nby, xcd, grid, b0, b1, b2, g0, g1,
+                         partial + used, done);
+      used += grid + g0 + g1 + g2;
+      MFS_LAUNCH_CHECK();
+      *nparts = used;
+      return MFS_OK;
     } else {
       hipLaunchKernelGGL((k_vcg_apply_fused<T, MASK>), dim3(grid), dim3(256), 0, st, h->cp, h->k1, h->k2, vv,
                          ob + h->off[0], ob + h->off[1], ob + h->off[2], xchunk, nbz, nby, xcd, partial + used, done);
@@ -665,17 +737,8 @@ static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial,
     }
   }
   // (2) the three slabs of interior faces outside that box: u at x = Nx-1, v at y = Ny-1, w at z = Nz-1
-  auto slab = [&](int ax) {
-    Box3 b;
-    for (int a = 0; a < 3; ++a) { b.lo[a] = 1; b.hi[a] = h->g.sh(ax, a) - 1; }
-    b.lo[ax] = h->g.N[ax] - 1;
-    b.hi[ax] = h->g.N[ax];
-    return b;
-  };
-  auto sgrid = [&](const Box3& b) {
-    const int64_t n = (int64_t)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(256, (n + 255) / 256));
-  };
+  auto slab = [&](int ax) { return vslab_box(h, ax); };
+  auto sgrid = [&](const Box3& b) { return vslab_grid(b); };
   if (Nx >= 3 && Ny >= 3 && Nz >= 3) {
     const Box3 b0 = slab(0), b1 = slab(1), b2 = slab(2);
     const int g0 = h->skip_top_x ? 0 : sgrid(b0), g1 = sgrid(b1), g2 = sgrid(b2);
@@ -1017,6 +1080,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->split_x = env_int("MFS_VISC_SPLIT_X", 1);
   h->skip_top_x = 0;
   h->p2p = nullptr;
+  h->merge_slabs = env_int("MFS_VISC_MERGE", 1);
   h->xchunk_tiled = std::max(1, env_int("MFS_VISC_XCHUNK", 32));
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
