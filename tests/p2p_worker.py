@@ -119,6 +119,39 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if os.environ.get("P2P_TEST_MODE") == "lost_peer_viscosity":
+        # fault injection, viscosity window loop: rank 1 maps its window and never takes part in the solve
+        from mfs import _lib
+        from mfs.dist import SlabVCG
+        from mfs.vcg import VcgEngine
+        import time as _t
+        try:
+            lg = (8, 12, 8)
+            eng = VcgEngine(lg, torch.float64, dev)
+            win = P2PWindow(dist, eng.edge_plane_bytes(), dev)
+            assert win.ok, win.why
+            if rank == 0:
+                dbl = tuple(2 * v + 1 for v in lg)
+                one = lambda sh: torch.ones(sh, dtype=torch.float64, device=dev)  # noqa: E731
+                eng.setup(1e-3, 1.0, one(dbl), one(dbl))
+                vecs = {n: eng.new_vector() for n in "bxdrq"}
+                vecs["b"][0].fill_(1.0)
+                eng.bind(*[vecs[n][0] for n in "bxdrq"])
+                cg = SlabVCG(eng, SlabPartition(14, 2, 0), vecs["d"][1], dist, window=win)
+                t0 = _t.perf_counter()
+                cg.begin(1e-12)
+                cg.iterate(4)
+                try:
+                    eng.poll()
+                    outcome = "no error"
+                except _lib.MfsError as exc:
+                    outcome = "MfsError: " + str(exc)
+                with open(f"{out}.rank0.txt", "w") as f:
+                    f.write(f"{_t.perf_counter() - t0:.3f}\n{outcome}\n")
+            win.close()
+        finally:
+            dist.destroy_process_group()
+        return
     if os.environ.get("P2P_TEST_MODE") == "lost_peer":
         # fault injection: rank 1 maps its window and then never takes part in the solve
         from mfs import _lib

@@ -159,12 +159,13 @@ def test_slab_solver_class_rccl_style_loop_over_gloo(tmp_path):
     np.testing.assert_allclose(res[0]["hist"], g["history"], rtol=1e-9)
 
 
-def test_lost_peer_is_reported_not_hung(tmp_path):
-    """fault injection: the neighbour never joins the solve -> every wait gives up after MFS_P2P_TIMEOUT_MS, later
-    kernels return at their top, and the next poll raises with status MFS_E_TIMEOUT (-4)."""
+@pytest.mark.parametrize("mode", ["lost_peer", "lost_peer_viscosity"])
+def test_lost_peer_is_reported_not_hung(mode, tmp_path):
+    """fault injection (pressure and viscosity window loops): the neighbour never joins the solve -> every wait gives up
+    after MFS_P2P_TIMEOUT_MS, later kernels return at their top, and the next poll raises with status MFS_E_TIMEOUT (-4)."""
     port = _free_port()
     out = str(tmp_path / "lost")
-    env = dict(os.environ, MFS_P2P_TIMEOUT_MS="400", P2P_TEST_MODE="lost_peer")
+    env = dict(os.environ, MFS_P2P_TIMEOUT_MS="400", P2P_TEST_MODE=mode)
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", str(port), "-", out, "f64"], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     try:
