@@ -32,4 +32,18 @@ for _ in range(rounds):
     for val, s in zip((va, vb), engs):
         t0 = time.perf_counter(); s._engine.iterate(iters); torch.cuda.synchronize()
         res[val].append(round((time.perf_counter() - t0) / iters * 1e6, 2))
-print(json.dumps({"N": N, "dtype": dts, "knob": var, "iter_us": res}))
+# where a difference sits: the phases of one iteration (collective-loop form of the same kernels), event-timed
+ph = {}
+for val, s in zip((va, vb), engs):
+    e = s._engine
+    out = {}
+    for name, fn in (("apply", e.phase_apply), ("xr", e.phase_update_xr), ("d", e.phase_update_d)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(); a.record()
+        for _ in range(20): fn()
+        b.record(); torch.cuda.synchronize()
+        out[name] = round(a.elapsed_time(b) / 20 * 1e3, 1)
+    f = s._flat
+    out["addr_mod_2MiB_KiB(b,x,d,r,q)"] = [int(f[n].data_ptr() % (2 << 20)) // 1024 for n in "bxdrq"]
+    ph[val] = out
+print(json.dumps({"N": N, "dtype": dts, "knob": var, "iter_us": res, "phase_us": ph}))
