@@ -252,7 +252,7 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
 // XUPD: this kernel also does `x += alpha d` (:212) -- the x update rides here instead of in k_update_xr (MODE 1
 // there), because d is already being read: 3 + 5 instead of 6 + 3 scalars per DOF for the two vector phases.
 // The values are the same (x_j + alpha_j d_j with the same alpha); on the converging iteration only x is updated.
-template <typename T, int VEC, bool XUPD = false>
+template <typename T, int VEC, bool XUPD = false, bool NTX = false>
 __global__ void __launch_bounds__(kBlock)
 k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __restrict__ scal,
            double* __restrict__ hist, int64_t hist_cap, int rev, int par, const double* __restrict__ part_rr,
@@ -280,10 +280,17 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
     if (vec) {
       Vec<T, VEC> dv = ldv<T, VEC>(d + i);
       if (XUPD) {
-        Vec<T, VEC> xv = ldv<T, VEC>(x + i);
+        if (NTX) {      // x is touched once per iteration and by no other kernel: stream it past the caches
+          vec_t<T, VEC> xn = vload_nt<T, VEC>(x + i);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) xv.v[j] = (T)((double)xv.v[j] + alpha_x * (double)dv.v[j]);
-        *reinterpret_cast<Vec<T, VEC>*>(x + i) = xv;
+          for (int j = 0; j < VEC; ++j) xn[j] = (T)((double)xn[j] + alpha_x * (double)dv.v[j]);
+          vstore_nt<T, VEC>(x + i, xn);
+        } else {
+          Vec<T, VEC> xv = ldv<T, VEC>(x + i);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) xv.v[j] = (T)((double)xv.v[j] + alpha_x * (double)dv.v[j]);
+          *reinterpret_cast<Vec<T, VEC>*>(x + i) = xv;
+        }
         if (conv) return;
       }
       const Vec<T, VEC> rv = ldv<T, VEC>(r + i);
@@ -397,6 +404,7 @@ struct CgCore {
   unsigned* tickets = nullptr;   // two sets of sharded arrival counters (kTicketWords each) for the in-launch reduction tails; zero between launches
   void *b = nullptr, *x = nullptr, *d = nullptr, *r = nullptr, *q = nullptr;
   int n_part_dq = 0, n_part_rr = 0;
+  int nt_xd = -1;                // direction + x update: x nontemporal (MFS_NT_XD: 0 / 1; -1 auto by size)
   int grid_vec = 2048, cus = 256;
   int64_t iter_enq = 0;        // iterations enqueued since begin (its parity selects the delta ring slot)
   int rev_xr = 0, rev_d = 0;   // sweep direction of the two vector phases (see for_each_vec)
@@ -422,6 +430,7 @@ static inline char* core_carve(CgCore& c, char* p) {
 
 static inline int core_init(CgCore& c, int dt, int64_t n) {
   c.dt = dt; c.n = n; c.elt = dtype_size(dt);
+  c.nt_xd = env_int("MFS_NT_XD", -1);
   int dev = 0;
   c.cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -519,11 +528,16 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
   const bool vec = core_vec_ok(c);
   const int grid = core_vec_grid(c, vec);
   if (xupd) {
-#define MFS_UD(TT, VV) \
-    hipLaunchKernelGGL((k_update_d<TT, VV, true>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
+#define MFS_UD(TT, VV, NN) \
+    hipLaunchKernelGGL((k_update_d<TT, VV, true, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
                        c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x)
-    if (c.dt == MFS_F32) { if (vec) MFS_UD(float, 4); else MFS_UD(float, 1); }
-    else                 { if (vec) MFS_UD(double, 2); else MFS_UD(double, 1); }
+    // x is touched once per iteration: streamed past the caches once the five vectors exceed the Infinity Cache
+    // (same-engine A/B, tools/visc_ab.py: viscosity 256^3 614 -> 589 us/iteration, 192^3 242.6 -> 237.0, 128^3 neutral).
+    // Read per launch so that the A/B tool can toggle it on one engine.
+    const int nt_knob = env_int("MFS_NT_XD", c.nt_xd);
+    const bool ntx = vec && (nt_knob < 0 ? 5.0 * (double)c.n * c.elt > 200e6 : nt_knob > 0);
+    if (c.dt == MFS_F32) { if (!vec) MFS_UD(float, 1, false); else if (ntx) MFS_UD(float, 4, true); else MFS_UD(float, 4, false); }
+    else                 { if (!vec) MFS_UD(double, 1, false); else if (ntx) MFS_UD(double, 2, true); else MFS_UD(double, 2, false); }
 #undef MFS_UD
     MFS_LAUNCH_CHECK();
     ++c.iter_enq;

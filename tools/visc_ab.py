@@ -32,6 +32,15 @@ for _ in range(rounds):
     for val, s in zip((va, vb), engs):
         t0 = time.perf_counter(); s._engine.iterate(iters); torch.cuda.synchronize()
         res[val].append(round((time.perf_counter() - t0) / iters * 1e6, 2))
+# knobs that the library reads per launch: the SAME engine (the first) with the variable toggled between loops --
+# no placement difference at all (at 256^3 the first-created solver of a process runs ~6 % faster than the second)
+same = {va: [], vb: []}
+for _ in range(rounds):
+    for val in (va, vb):
+        os.environ[var] = val
+        s = engs[0]
+        t0 = time.perf_counter(); s._engine.iterate(iters); torch.cuda.synchronize()
+        same[val].append(round((time.perf_counter() - t0) / iters * 1e6, 2))
 # where a difference sits: the phases of one iteration (collective-loop form of the same kernels), event-timed
 ph = {}
 for val, s in zip((va, vb), engs):
@@ -46,4 +55,4 @@ for val, s in zip((va, vb), engs):
     f = s._flat
     out["addr_mod_2MiB_KiB(b,x,d,r,q)"] = [int(f[n].data_ptr() % (2 << 20)) // 1024 for n in "bxdrq"]
     ph[val] = out
-print(json.dumps({"N": N, "dtype": dts, "knob": var, "iter_us": res, "phase_us": ph}))
+print(json.dumps({"N": N, "dtype": dts, "knob": var, "iter_us": res, "same_engine_toggled_iter_us": same, "phase_us": ph}))
