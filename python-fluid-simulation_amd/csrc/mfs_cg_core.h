@@ -212,7 +212,8 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
       }
       if (MODE != 2) {
         vec_t<T, VEC> rv = vload<T, VEC>(r + i);
-        const vec_t<T, VEC> qv = vload<T, VEC>(q + i);
+        // MODE 1 with NTX (x is not touched here): q -- written by the apply, read only here -- is streamed instead
+        const vec_t<T, VEC> qv = (MODE == 1 && NTX) ? vload_nt<T, VEC>(q + i) : vload<T, VEC>(q + i);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
@@ -513,7 +514,14 @@ static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode 
     const int64_t per = vec ? (c.dt == MFS_F32 ? 4 : 2) : 1;
     grid = std::max(1, (int)std::min<int64_t>(grid, std::max<int64_t>(c.cus, cnt / per / (kBlock * c.xr_vpt))));
   }
-  const bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
+  bool ntx = c.nt_x < 0 ? (5.0 * (double)c.n * c.elt > 200e6) : (c.nt_x != 0);
+  if (mode == 1) {
+    // r-only form: the flag streams q.  Pays only when one vector is far beyond what the Infinity Cache keeps between
+    // the apply and this kernel (A/B: viscosity 256^3, 201 MB vectors, 642 -> 631 us/iteration; pressure 256^3, 67 MB
+    // vectors, 125.0 -> 127.9 us: q is still on-die there).  MFS_NT_Q = 0 / 1 overrides (read per launch).
+    const int knob = env_int("MFS_NT_Q", -1);
+    ntx = knob < 0 ? ((double)c.n * c.elt > 128e6) : (knob != 0);
+  }
   if (mode == 1) { MFS_XR_MODE(1) } else if (mode == 2) { MFS_XR_MODE(2) } else { MFS_XR_MODE(0) }
   MFS_LAUNCH_CHECK();
   if (mode != 2) c.n_part_rr = grid;
