@@ -102,9 +102,12 @@ template <> struct Gran<double> { static constexpr int N = 2; };
 // 16-byte write-through store of TWO granules: a store torn between its 8-byte halves is harmless (each half
 // validates itself), and 16-byte lanes move ~2.7x the bytes per instruction slot of 8-byte ones.
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+// The trailing s_nop is part of the instruction's contract, not padding: a VMEM store of more than 64 bits reads its data
+// VGPRs after issue, and a VALU write to them in the next slot corrupts the payload (CDNA ISA, manually inserted wait
+// states).  The compiler inserts that wait state for its own stores but cannot see into an asm statement.
 __device__ __forceinline__ void sys_store2(u64* p, u64 a, u64 b) {
   u64x2 v = {a, b};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 template <typename T, int VEC>
