@@ -18,7 +18,7 @@ dev = torch.device("cuda", 0 if shared else int(os.environ.get("LOCAL_RANK", "0"
 torch.cuda.set_device(dev)
 dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
 tdt = torch.float32 if dts == "f32" else torch.float64
-ggrid = {1: (256, 256, 256), 2: (512, 256, 256), 4: (512, 512, 256), 8: (512, 512, 512)}[world]
+ggrid = {1: (256, 256, 256), 2: (512, 256, 256), 4: (512, 512, 256), 8: (512, 512, 512)}.get(world, (256 * world, 256, 256))
 if os.environ.get("SLAB_REPRO_GRID"):
     ggrid = tuple(int(v) for v in os.environ["SLAB_REPRO_GRID"].split(","))
 part = mdist.SlabPartition(ggrid[0], world, rank)
