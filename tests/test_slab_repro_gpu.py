@@ -33,3 +33,16 @@ def test_window_loop_is_reproducible_under_load(dtype):
     assert out["world"] == 4 and out["grid"] == [512, 512, 256]
     assert out["rccl_vs_rccl"] == 0.0 and out["p2p_vs_p2p"] == 0.0, out
     assert out["p2p_vs_rccl"] < 1e-12, out
+
+
+def test_slab_viscosity_solve_is_reproducible_under_load():
+    """the whole slab viscosity solve (3 ranks sharing the GPU, 96^3, fp32 state) twice per transport: bit-identical within
+    a transport, summation-order level between the window and the collective transport"""
+    env = dict(os.environ, MFS_BENCH_SHARED_GPU="1", MFS_P2P_TIMEOUT_MS="20000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tools", "vslab_repro.py"), "96", "f32"]
+    p = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=400)
+    assert p.returncode == 0, p.stdout[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["p2p_identical"] and out["rccl_identical"], out
+    assert len(set(out["iterations"])) == 1 and out["p2p_vs_rccl_first_entries"] < 1e-12, out
