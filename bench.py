@@ -195,10 +195,14 @@ def main():
                 cg_p2p.begin(0.0)
                 cg_p2p.iterate(V)
                 h_p = eng.history()[: 2 * V + 1]
+                cg_p2p.begin(0.0)                 # ... and once more: the window loop must reproduce itself bit for bit
+                cg_p2p.iterate(V)
+                h_p2 = eng.history()[: 2 * V + 1]
+                tinfo["p2p_reproducible"] = bool(len(h_p2) == len(h_p) and (h_p2 == h_p).all())
                 dev_rel = float(abs(h_p - h_r).max() / abs(h_r).max()) if len(h_p) == len(h_r) == 2 * V + 1 else float("nan")
                 # both loops do the same arithmetic per cell and differ only in the order of the dot products' partial
                 # sums: 1e-16 .. 1e-15 in either state precision; anything visibly larger is a transport fault
-                ok = dev_rel == dev_rel and max(abs(h_p - h_r) / abs(h_r)) < 1e-9
+                ok = dev_rel == dev_rel and max(abs(h_p - h_r) / abs(h_r)) < 1e-9 and tinfo["p2p_reproducible"]
             except _lib.MfsError as exc:
                 tinfo["p2p_error"] = str(exc)[:300]
             ok = agree(ok)
