@@ -211,7 +211,7 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
         if (NTX) vstore_nt<T, VEC>(x + i, xv); else vstore<T, VEC>(x + i, xv);
       }
       if (MODE != 2) {
-        vec_t<T, VEC> rv = vload<T, VEC>(r + i);
+        vec_t<T, VEC> rv = vload<T, VEC>(r + i);     // (streaming r here as well: no gain for viscosity, -1 % for pressure)
         // MODE 1 with NTX (x is not touched here): q -- written by the apply, read only here -- is streamed instead
         const vec_t<T, VEC> qv = (MODE == 1 && NTX) ? vload_nt<T, VEC>(q + i) : vload<T, VEC>(q + i);
 #pragma unroll
@@ -257,7 +257,7 @@ template <typename T, int VEC, bool XUPD = false, bool NTX = false>
 __global__ void __launch_bounds__(kBlock)
 k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __restrict__ scal,
            double* __restrict__ hist, int64_t hist_cap, int rev, int par, const double* __restrict__ part_rr,
-           int npart, T* __restrict__ x = nullptr) {
+           int npart, T* __restrict__ x = nullptr, int nt_r = 0) {
   if (scal[S_DONE] != 0.0) return;
   const double rr = npart > 0 ? block_total_of(part_rr, npart) : scal[S_RR];
   const double delta = scal[S_RING + par], tol2 = scal[S_TOL2];
@@ -294,7 +294,14 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
         }
         if (conv) return;
       }
-      const Vec<T, VEC> rv = ldv<T, VEC>(r + i);
+      Vec<T, VEC> rv;
+      if (XUPD && nt_r) {      // r streamed too (MFS_NT_RD; auto by size)
+        const vec_t<T, VEC> rn = vload_nt<T, VEC>(r + i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rv.v[j] = rn[j];
+      } else {
+        rv = ldv<T, VEC>(r + i);
+      }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) dv.v[j] = (T)((double)rv.v[j] + beta * (double)dv.v[j]);
       *reinterpret_cast<Vec<T, VEC>*>(d + i) = dv;
@@ -538,7 +545,10 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
   if (xupd) {
 #define MFS_UD(TT, VV, NN) \
     hipLaunchKernelGGL((k_update_d<TT, VV, true, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
-                       c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x)
+                       c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r)
+    // ... and so is r here (same-engine A/B: viscosity 256^3 632.8 -> 596.6 us/iteration, 192^3 250.0 -> 243.6)
+    const int nt_r_knob = env_int("MFS_NT_RD", -1);
+    const int nt_r = vec && (nt_r_knob < 0 ? 5.0 * (double)c.n * c.elt > 200e6 : nt_r_knob > 0);
     // x is touched once per iteration: streamed past the caches once the five vectors exceed the Infinity Cache
     // (same-engine A/B, tools/visc_ab.py: viscosity 256^3 614 -> 589 us/iteration, 192^3 242.6 -> 237.0, 128^3 neutral).
     // Read per launch so that the A/B tool can toggle it on one engine.
