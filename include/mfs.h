@@ -39,7 +39,11 @@ typedef enum {
   MFS_E_INVALID = -1,     /* bad argument (null pointer, bad dtype, bad size, misuse) */
   MFS_E_HIP = -2,         /* a HIP runtime call failed; see mfs_last_error() */
   MFS_E_NODEVICE = -3,    /* no gfx950 device visible */
-  MFS_E_TIMEOUT = -4      /* slab loop: a peer GPU did not answer within MFS_P2P_TIMEOUT_MS; the solve was stopped */
+  MFS_E_TIMEOUT = -4,     /* slab loop: a peer GPU did not answer within MFS_P2P_TIMEOUT_MS; the solve was stopped */
+  MFS_E_ZERODIV = -5,     /* CG: d.q == 0 -- the reference's `alpha = delta / dq` raises ZeroDivisionError
+                             (PressureCGSolver3D.py:211, ViscosityCGSolver3D.py:594); returned by the next poll / solve */
+  MFS_E_NONFINITE = -6    /* CG: d.q or r.r is NaN / inf (poisoned input).  The reference would iterate to max_iter on
+                             `nan < tol**2` and then raise ValueError("Failed to converge!"); the device loop stops at once */
 } mfs_status;
 
 typedef void* mfs_stream; /* hipStream_t */
@@ -163,7 +167,8 @@ int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream);
 #define MFS_PCG_S_ALPHA 6
 #define MFS_PCG_S_BETA 7
 #define MFS_PCG_S_LASTRR 8  /* r.r of the last completed iteration (what the reference keeps in self.delta) */
-#define MFS_PCG_S_ERR 11    /* != 0: a peer-to-peer wait of the slab loop timed out */
+#define MFS_PCG_S_ERR 11    /* != 0: the device loop stopped itself: 1 / 2 a peer-to-peer wait of the slab loop timed out,
+                               3 d.q == 0, 4 non-finite d.q or r.r */
 void* mfs_pcg3d_scalars(mfs_pcg3d* h);
 /* performance knobs of the stencil kernel (results are identical for every setting):
  * variant 0 = direct loads, 1 = x-marching in registers, 2 = x-marching + LDS-staged

@@ -42,7 +42,19 @@ enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TO
        S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
        S_LASTRR = MFS_PCG_S_LASTRR, S_RING = 9 /* 2 slots: delta by iteration parity */,
        S_RZ = 12 /* Jacobi loop: r.z of the latest update */,
-       S_ERR = MFS_PCG_S_ERR /* != 0: a peer-to-peer wait timed out (slab loop); the solve is stopped */ };
+       S_ERR = MFS_PCG_S_ERR /* != 0: the solve was stopped -- 1 / 2 a peer-to-peer wait timed out (slab loop: all-reduce /
+                                halo plane), 3 d.q == 0 (the reference's ZeroDivisionError, PressureCGSolver3D.py:211),
+                                4 a non-finite d.q or r.r (the reference would spin to max_iter on `nan < tol**2`) */ };
+enum { kErrArTimeout = 1, kErrHaloTimeout = 2, kErrZeroDq = 3, kErrNonFinite = 4 };
+
+// health of the two dot products that close an iteration: 0 fine, else the S_ERR code.  Detected on the device so that
+// a poisoned solve stops within one `check_every` instead of iterating to max_iter = prod(gres).
+__device__ __forceinline__ int cg_health(double dq, double rr) {
+  const double big = 1.7976931348623157e308;
+  if (dq == 0.0) return kErrZeroDq;
+  if (!(fabs(dq) <= big) || !(fabs(rr) <= big)) return kErrNonFinite;
+  return 0;
+}
 
 
 template <typename T, int VEC>
@@ -106,10 +118,16 @@ __device__ __forceinline__ double block_total_of(const double* __restrict__ part
 // returns true -- to every thread -- in exactly ONE block, the last to arrive, where *total is the sum
 // of partial[0..count) in block_total_of's order (so the value is the one a following kernel would
 // compute).  Hand-off: write-through (sc1) partial store, drained, then a relaxed agent-scope ticket;
-// the block whose ticket is the last reads every partial with sc1 loads behind a workgroup barrier.
+// the lane that drew the last ticket performs ONE agent-scope acquire (buffer_inv sc1) and waits for it before the
+// workgroup barrier that releases the other waves' loads of the partials (the consumer form of
+// cdna_hip_programming.md Guideline 16; the guide validates dropping the acquire for sc1 loads only on a single
+// unsharded last-arriver counter, which this two-level ticket is not -- so the acquire stays, in one block per launch).
 // Arrival tickets are SHARDED: one returning atomic costs ~12 ns on its word, so 2048 arrivals on one counter would
 // serialise for ~25 us -- longer than a small grid's whole update kernel.  Blocks b with equal b % 8 (the blocks of one
 // XCD) share a shard counter on a cache line of its own; the last arriver of each shard draws a top-level ticket.
+#ifndef MFS_TAIL_ACQUIRE
+#define MFS_TAIL_ACQUIRE 1      // 0: A/B builds only (tools/iter_sweep.py with MFS_LIB)
+#endif
 constexpr int kTicketStride = 32;                       // unsigned words between counters (128 bytes)
 constexpr int kTicketWords = 9 * kTicketStride;         // 8 shards + the top-level counter
 
@@ -132,6 +150,10 @@ __device__ __forceinline__ bool last_block_total(double* __restrict__ partial, i
         __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // re-arm the top
         last = true;
       }
+    }
+    if (last && MFS_TAIL_ACQUIRE) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the invalidate has completed before the barrier opens
     }
     s_last = last;
   }
@@ -160,6 +182,7 @@ __device__ __forceinline__ void cg_book(double* __restrict__ scal, double* __res
   scal[S_DELTA] = delta;
   scal[S_LASTRR] = rr;
   scal[S_ALPHA] = delta / dq;
+  if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; return; }
   if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rr / delta;
 }
 
@@ -257,8 +280,15 @@ template <typename T, int VEC, bool XUPD = false, bool NTX = false>
 __global__ void __launch_bounds__(kBlock)
 k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __restrict__ scal,
            double* __restrict__ hist, int64_t hist_cap, int rev, int par, const double* __restrict__ part_rr,
-           int npart, T* __restrict__ x = nullptr, int nt_r = 0) {
-  if (scal[S_DONE] != 0.0) return;
+           int npart, T* __restrict__ x = nullptr, int nt_r = 0, double own_mark = 1.0) {
+  // `done` is raised by THIS kernel's bookkeeping thread on the converging iteration, and with XUPD the other blocks
+  // still owe the final x += alpha d: a block that starts after that store must not mistake it for an older one.
+  // The marker written here is unique to the launch (own_mark = -(iteration + 1); every other writer stores +1), a
+  // block returns at the top only for a marker that is not its own.  (A kernel must not test a flag it writes itself.)
+  {
+    const double dn = scal[S_DONE];
+    if (dn != 0.0 && !(XUPD && dn == own_mark)) return;
+  }
   const double rr = npart > 0 ? block_total_of(part_rr, npart) : scal[S_RR];
   const double delta = scal[S_RING + par], tol2 = scal[S_TOL2];
   const bool conv = rr < tol2;
@@ -274,7 +304,8 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
     scal[S_DELTA] = delta;
     scal[S_LASTRR] = rr;
     scal[S_ALPHA] = delta / dq;
-    if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
+    if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
+    else if (conv) scal[S_DONE] = XUPD ? own_mark : 1.0; else scal[S_BETA] = beta;
   }
   if (conv && !XUPD) return;
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
@@ -545,7 +576,8 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
   if (xupd) {
 #define MFS_UD(TT, VV, NN) \
     hipLaunchKernelGGL((k_update_d<TT, VV, true, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
-                       c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r)
+                       c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r, \
+                       -(double)(c.iter_enq + 1))
     // ... and so is r here (same-engine A/B: viscosity 256^3 632.8 -> 596.6 us/iteration, 192^3 250.0 -> 243.6)
     const int nt_r_knob = env_int("MFS_NT_RD", -1);
     const int nt_r = vec && (nt_r_knob < 0 ? 5.0 * (double)c.n * c.elt > 200e6 : nt_r_knob > 0);
@@ -633,7 +665,18 @@ static inline int core_poll(CgCore& c, hipStream_t st, int64_t* iters, int* done
   MFS_HIP_TRY(hipMemcpyAsync(c.pinned, c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
   MFS_HIP_TRY(hipStreamSynchronize(st));
   if (c.pinned[S_ERR] != 0.0) {
-    set_error("peer-to-peer wait timed out inside the CG loop (code %d: 1 = all-reduce, 2 = halo plane)", (int)c.pinned[S_ERR]);
+    const int code = (int)c.pinned[S_ERR];
+    if (code == kErrZeroDq) {
+      set_error("d.q == 0 in CG iteration %lld: float division by zero (the reference raises ZeroDivisionError at "
+                "alpha = delta / dq)", (long long)c.pinned[S_ITERS]);
+      return MFS_E_ZERODIV;
+    }
+    if (code == kErrNonFinite) {
+      set_error("non-finite d.q or r.r in CG iteration %lld (NaN / inf in the inputs): the solve was stopped",
+                (long long)c.pinned[S_ITERS]);
+      return MFS_E_NONFINITE;
+    }
+    set_error("peer-to-peer wait timed out inside the CG loop (code %d: 1 = all-reduce, 2 = halo plane)", code);
     return MFS_E_TIMEOUT;
   }
   if (iters) *iters = (int64_t)c.pinned[S_ITERS];

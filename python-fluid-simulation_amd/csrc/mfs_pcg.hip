@@ -161,7 +161,8 @@ k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__
     scal[S_DELTA] = delta;
     scal[S_LASTRR] = rr;
     scal[S_ALPHA] = delta / dq;
-    if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
+    if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
+    else if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
   }
   if (conv) return;
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {

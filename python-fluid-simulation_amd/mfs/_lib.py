@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MFS_LIB") or os.path.join(_HERE, "libmfs_hip.so")   #
 
 MFS_F32, MFS_F64 = 0, 1
 MFS_OK, MFS_NOT_CONVERGED = 0, 1
-MFS_E_TIMEOUT = -4
+MFS_E_TIMEOUT, MFS_E_ZERODIV, MFS_E_NONFINITE = -4, -5, -6
 ABI_VERSION = 1
 
 # scalar slots of the CG engine's device block (include/mfs.h)
@@ -28,6 +28,24 @@ NSCALARS = 16
 
 class MfsError(RuntimeError):
     pass
+
+
+class MfsTimeout(MfsError, TimeoutError):
+    """MFS_E_TIMEOUT: a peer rank did not answer (window loop: MFS_P2P_TIMEOUT_MS; collective loop:
+    MFS_COLLECTIVE_TIMEOUT_S).  The solve was stopped; nothing is left spinning on the GPU."""
+    status = MFS_E_TIMEOUT
+
+
+class MfsZeroDivision(ZeroDivisionError):
+    """MFS_E_ZERODIV: d.q == 0 inside the CG loop.  The reference's `alpha = self.delta / cp.sum(d*q).item()`
+    raises ZeroDivisionError there (solver/PressureCGSolver3D.py:211); so do the drop-ins."""
+
+
+class MfsNonFinite(FloatingPointError, ValueError):
+    """MFS_E_NONFINITE: d.q or r.r became NaN / inf (poisoned inputs).  The reference never sees `nan < tol**2`
+    come true, iterates max_iter = prod(gres) times and raises ValueError("Failed to converge!")
+    (PressureCGSolver3D.py:222-223); the device loop stops at the first non-finite dot product instead.  Subclass of
+    both FloatingPointError (what happened) and ValueError (what the reference's caller would have caught)."""
 
 
 _p, _i, _i64, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
@@ -178,7 +196,12 @@ def check(status, what=""):
     """Raise MfsError for negative statuses; returns the status otherwise."""
     if status < 0:
         msg = load().mfs_last_error().decode(errors="replace")
-        raise MfsError(f"{what or 'libmfs_hip'} failed with status {status}: {msg}")
+        if status == MFS_E_ZERODIV:
+            raise MfsZeroDivision(f"float division by zero ({what}: {msg})")
+        if status == MFS_E_NONFINITE:
+            raise MfsNonFinite(f"Failed to converge! ({what}: {msg})")
+        cls = MfsTimeout if status == MFS_E_TIMEOUT else MfsError
+        raise cls(f"{what or 'libmfs_hip'} failed with status {status}: {msg}")
     return status
 
 

@@ -30,7 +30,77 @@ the neighbour's own update, so the final velocity update finds p[x-1] in place.
 """
 from __future__ import annotations
 
+import datetime
+import os
+import time
+import warnings
+
 from . import _lib
+
+
+def collective_timeout_s():
+    """bound on every wait of the collective ("rccl") loops: MFS_COLLECTIVE_TIMEOUT_S, default 60 s"""
+    return float(os.environ.get("MFS_COLLECTIVE_TIMEOUT_S", "60"))
+
+
+def pg_timeout():
+    """`timeout=` for init_process_group in the launchers (bench.py, tools, test workers): the backend's own bound
+    (gloo: every blocking call; nccl: the watchdog that aborts a communicator whose collective never completes)"""
+    return datetime.timedelta(seconds=max(30.0, 2.0 * collective_timeout_s()))
+
+
+class _BoundedCollectives:
+    """Bounded waits for the collective loops of SlabCG / SlabVCG.  A lost peer must surface as MfsTimeout (status
+    MFS_E_TIMEOUT, like the window loop's bounded spins), never as a process blocked in a collective:
+      * host-blocking backends (gloo: tests, rehearsals): every collective runs async_op=True and is awaited with
+        work.wait(timeout);
+      * "nccl" (RCCL): a wait only orders the compute stream behind the collective, the host runs ahead -- so the
+        bound sits where the host does block, at the poll: the stream is drained with an event polled against a
+        deadline (`drain`), and the group's own timeout (pg_timeout) lets the watchdog abort the stuck communicator."""
+
+    def _bc_init(self):
+        self.timeout_s = collective_timeout_s()
+
+    def _blocking_backend(self):
+        return self.dist.get_backend(self.group) != "nccl"
+
+    def _timed_out(self, what, exc=None):
+        msg = (f"{what} failed with status {_lib.MFS_E_TIMEOUT}: collective wait timed out after {self.timeout_s:g} s "
+               f"on rank {self.part.rank} of {self.part.world} (a peer rank is lost or stuck; MFS_COLLECTIVE_TIMEOUT_S)")
+        if exc is not None:
+            msg += f" [{type(exc).__name__}: {str(exc)[:200]}]"
+        return _lib.MfsTimeout(msg)
+
+    def _wait(self, work, what):
+        if work is None:
+            return
+        if not self._blocking_backend():
+            work.wait()                       # stream-ordered; bounded at drain()
+            return
+        try:
+            ok = work.wait(timeout=datetime.timedelta(seconds=self.timeout_s))
+        except RuntimeError as exc:           # gloo raises on timeout / on a peer that closed its connection
+            raise self._timed_out(what, exc) from None
+        if ok is False:
+            raise self._timed_out(what)
+
+    def _allreduce_bounded(self, t, what):
+        self._wait(self.dist.all_reduce(t, group=self.group, async_op=True), what)
+
+    def drain(self, what="CG loop"):
+        """wait, bounded, until this rank's stream has executed everything enqueued so far"""
+        sc = getattr(self.ops, "scalars", None)
+        if sc is None or not getattr(sc, "is_cuda", False):
+            return
+        import torch
+        ev = torch.cuda.Event()
+        ev.record()
+        deadline = time.monotonic() + self.timeout_s
+        while not ev.query():
+            if time.monotonic() > deadline:
+                raise self._timed_out(what)
+            time.sleep(2e-4)
+
 
 
 class SlabPartition:
@@ -55,7 +125,7 @@ class SlabPartition:
         return int(ggrid[0]) * int(ggrid[1]) * int(ggrid[2])
 
 
-class SlabCG:
+class SlabCG(_BoundedCollectives):
     """CG iterations over one slab.  `ops` is the engine (mfs.pcg.PcgEngine on the
     GPU): begin_local/begin_finish/phase_*/iterate plus a `scalars` tensor that the
     all-reduces act on.  `d` is the local direction vector (planes 0 and L-1 are
@@ -75,14 +145,25 @@ class SlabCG:
         self.window = window if (window is not None and window.ok) else None
         if self.window is not None:
             ops.attach_p2p(self.window)
+        self._bc_init()
+        self._p2p_active = None          # which loop the last begin() / solve() took (None: none yet)
+        self.downgraded = ""             # why a given window is NOT being used (empty: it is, or none was given)
 
     @property
     def mode(self):
-        return "p2p" if self.window is not None else ("rccl" if self.multi else "single")
+        """the transport of the loop that runs: after begin() / solve() what was taken, before it what would be"""
+        p2p = self._p2p_active if self._p2p_active is not None else self._p2p()
+        return "p2p" if p2p else ("rccl" if (self.multi or (self.window is not None and self.dist is not None)) else "single")
 
+    def _note_downgrade(self):
+        if self.window is not None and not self.downgraded:
+            self.downgraded = ("the engine as bound cannot run the window loop (needs the fused direction update, "
+                               "the vector path, stencil variant 2, no Jacobi, matching plane size): collective loop")
+            warnings.warn(f"SlabCG rank {self.part.rank}: p2p window given but not usable -- {self.downgraded}",
+                          RuntimeWarning, stacklevel=3)
 
     def _allreduce(self, slot):
-        self.dist.all_reduce(self.ops.scalars[slot:slot + 1], group=self.group)
+        self._allreduce_bounded(self.ops.scalars[slot:slot + 1], f"all-reduce of CG scalar {slot}")
 
     def _halo_start(self):
         """start the exchange of d's two edge planes; returns the function that completes it.  RCCL moves the device
@@ -101,7 +182,7 @@ class SlabCG:
 
         def finish():
             for w in reqs:
-                w.wait()
+                self._wait(w, "halo exchange of d")
             if staged:
                 if p.left is not None:
                     d[0].copy_(src[0])
@@ -120,6 +201,9 @@ class SlabCG:
             self.ops.slab_begin(tol)
             return
         self._p2p_active = False
+        if self.window is not None and self.dist is not None:
+            self._note_downgrade()
+            self.multi = True                  # a window was given but cannot be used: the collective loop
         if not self.multi:
             self.ops.begin_local(tol)
             self.ops.begin_finish()
@@ -159,7 +243,7 @@ class SlabCG:
                 work = self.dist.all_reduce(self.ops.scalars[_lib.S_RR:_lib.S_RR + 1], group=self.group,
                                             async_op=True)
                 ops.phase_update_x()
-                work.wait()
+                self._wait(work, "all-reduce of r.r")
             else:
                 ops.phase_update_xr()
                 ops.phase_reduce(1)
@@ -180,16 +264,19 @@ class SlabCG:
             return self.ops.slab_solve(tol, max_iter, check_every)
         self._p2p_active = False
         if self.window is not None and self.dist is not None:
+            self._note_downgrade()
             self.multi = True                  # a window was given but cannot be used: the collective loop
         if not self.multi:
             return self.ops.solve(tol, max_iter, check_every)
         self.begin(tol)
+        self.drain()
         st = self.ops.poll()
         enq = 0
         while not st["done"] and enq < max_iter:
             n = min(int(check_every), int(max_iter) - enq)
             self.iterate(n)
             enq += n
+            self.drain()
             st = self.ops.poll()
         return bool(st["done"]), int(st["iterations"])
 
@@ -213,7 +300,7 @@ class SlabCG:
             ops.append(dist.P2POp(dist.isend, src[L - 2], p.right, self.group))
             ops.append(dist.P2POp(dist.irecv, src[L - 1], p.right, self.group))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
-            w.wait()
+            self._wait(w, "halo exchange")
         if staged:
             if p.left is not None:
                 t[0].copy_(src[0])
@@ -221,7 +308,7 @@ class SlabCG:
                 t[L - 1].copy_(src[L - 1])
 
 
-def exchange_edge_planes(dist, group, part, fields, L):
+def exchange_edge_planes(dist, group, part, fields, L, wait=None):
     """Halo exchange of several local fields at once: for each tensor (first axis = local plane index, planes 0 and
     L-1 ghost / boundary) plane 1 goes to the left neighbour's plane L'-1 and plane L-2 to the right neighbour's
     plane 0.  One batch of sends / receives for all fields.  RCCL moves device planes; any other backend (gloo
@@ -239,7 +326,10 @@ def exchange_edge_planes(dist, group, part, fields, L):
             ops.append(dist.P2POp(dist.isend, src[L - 2], part.right, group))
             ops.append(dist.P2POp(dist.irecv, src[L - 1], part.right, group))
     for w in (dist.batch_isend_irecv(ops) if ops else []):
-        w.wait()
+        if wait is not None:
+            wait(w, "halo exchange")           # bounded (SlabVCG / SlabCG._wait)
+        else:
+            w.wait()
     if staged:
         for t, src in zip(fields, srcs):
             if part.left is not None:
@@ -248,7 +338,7 @@ def exchange_edge_planes(dist, group, part, fields, L):
                 t[L - 1].copy_(src[L - 1])
 
 
-class SlabVCG:
+class SlabVCG(_BoundedCollectives):
     """The viscosity CG (three staggered components) over one x-slab: the same decomposition as SlabCG.
 
     Rank p holds cell planes [a_p - 1, a_{p+1} + 1) of the global grid (L planes), hence u (x-face) planes
@@ -276,6 +366,7 @@ class SlabVCG:
         self.window = window if (window is not None and window.ok) else None
         if self.window is not None:
             ops.attach_p2p(self.window)
+        self._bc_init()
 
     @property
     def mode(self):
@@ -283,10 +374,11 @@ class SlabVCG:
 
     def _allreduce(self, slot):
         if self.multi:
-            self.dist.all_reduce(self.ops.scalars[slot:slot + 1], group=self.group)
+            self._allreduce_bounded(self.ops.scalars[slot:slot + 1], f"all-reduce of CG scalar {slot}")
 
     def exchange(self, fields):
-        exchange_edge_planes(self.dist if self.multi else None, self.group, self.part, list(fields), self.L)
+        exchange_edge_planes(self.dist if self.multi else None, self.group, self.part, list(fields), self.L,
+                             wait=self._wait)
 
     def begin(self, tol):
         if self.window is not None:
@@ -314,11 +406,16 @@ class SlabVCG:
     def solve(self, tol, max_iter, check_every=32):
         """COLLECTIVE; returns (converged, iterations).  Every rank tests the same all-reduced scalars."""
         self.begin(tol)
+        bounded = self.multi and self.window is None      # the window loop bounds its own waits on the device
+        if bounded:
+            self.drain()
         st = self.ops.poll()
         enq = 0
         while not st["done"] and enq < max_iter:
             n = min(int(check_every), int(max_iter) - enq)
             self.iterate(n)
             enq += n
+            if bounded:
+                self.drain()
             st = self.ops.poll()
         return bool(st["done"]), int(st["iterations"])

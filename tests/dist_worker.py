@@ -288,6 +288,37 @@ def local_problem(gl, part):
     return loc
 
 
+def run_lost_peer(rank, world, port, path, timeout_s):
+    """fault injection for the COLLECTIVE loop: rank 1 joins the group and then never takes part in the solve.  Rank 0
+    must get MfsTimeout (status MFS_E_TIMEOUT) out of begin() / iterate() within the bound -- not a blocked process."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MFS_COLLECTIVE_TIMEOUT_S"] = str(timeout_s)
+    from mfs.dist import pg_timeout
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout())
+    with np.load(path, allow_pickle=False) as z:
+        gl = {k: z[k] for k in z.files}
+    gl["gres"] = tuple(int(v) for v in gl["gres"])
+    part = SlabPartition(gl["gres"][0], world, rank)
+    if rank == 0:
+        loc = local_problem(gl, part)
+        ops = OracleSlabOps(loc["gres"], loc["lphi"], loc["wx"], loc["wy"], loc["wz"], loc["b"])
+        cg = SlabCG(ops, part, ops.d, dist)
+        t0 = time.perf_counter()
+        try:
+            cg.begin(1e-9)
+            cg.iterate(4)
+            outcome = "no error"
+        except _lib.MfsError as exc:
+            outcome = f"{type(exc).__name__}: {exc}"
+        with open(f"{path}.rank0.txt", "w") as f:
+            f.write(f"{time.perf_counter() - t0:.3f}\n{outcome}\n")
+    else:
+        time.sleep(float(timeout_s) + 3.0)      # alive (the connection stays open), but never in the solve
+    os._exit(0)                                 # no collective teardown with a peer that has given up
+
+
 def run(rank, world, port, path, tol, overlap, max_iter):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -288,6 +288,11 @@ CASES = [
     ("v3d_c_16_mu50", lambda n: gen_viscosity3d(n, (16, 16, 16), 5, np.float32, mu=50.0)),
     ("d3d_a_12", lambda n: gen_density3d(n, (12, 12, 12), 9)),
     ("d3d_b_10x12x14_f32", lambda n: gen_density3d(n, (10, 12, 14), 10, per_cell=3, px_dtype=np.float32)),
+    # round 2: cases that span more than one tile of the march kernels ("N = 32-48 are practical")
+    ("p3d_f_40x36x32_sv", lambda n: gen_pressure3d(n, (40, 36, 32), 12, np.float32, True)),
+    ("v3d_d_24", lambda n: gen_viscosity3d(n, (24, 24, 24), 13, np.float32)),
+    ("v3d_e_20x24x36_mu20", lambda n: gen_viscosity3d(n, (20, 24, 36), 14, np.float64, mu=20.0)),
+    ("d3d_c_20", lambda n: gen_density3d(n, (20, 20, 20), 15)),
 ]
 
 if __name__ == "__main__":

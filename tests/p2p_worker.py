@@ -112,13 +112,25 @@ def timestep_mode(rank, world, path, out, dtname, dev):
     sim.close()
 
 
+def _close_after_fault(win):
+    """teardown of the fault-injection modes: the group may be broken by the timed-out collective (gloo closes the
+    pair), so the window's closing barrier is best-effort and the process leaves without a collective teardown."""
+    try:
+        win.close()
+    except Exception as exc:  # noqa: BLE001
+        print(f"window close after the injected fault: {type(exc).__name__}", flush=True)
+    sys.stdout.flush()
+    os._exit(0)
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     path, out, dtname = sys.argv[4], sys.argv[5], sys.argv[6]
     tdt = {"f64": torch.float64, "f32": torch.float32}[dtname]
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from mfs.dist import pg_timeout
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=pg_timeout())
     if os.environ.get("P2P_TEST_MODE") == "lost_peer_viscosity":
         # fault injection, viscosity window loop: rank 1 maps its window and never takes part in the solve
         from mfs import _lib
@@ -139,18 +151,19 @@ def main():
                 eng.bind(*[vecs[n][0] for n in "bxdrq"])
                 cg = SlabVCG(eng, SlabPartition(14, 2, 0), vecs["d"][1], dist, window=win)
                 t0 = _t.perf_counter()
-                cg.begin(1e-12)
-                cg.iterate(4)
                 try:
+                    cg.begin(1e-12)
+                    cg.iterate(4)
                     eng.poll()
                     outcome = "no error"
                 except _lib.MfsError as exc:
                     outcome = "MfsError: " + str(exc)
                 with open(f"{out}.rank0.txt", "w") as f:
                     f.write(f"{_t.perf_counter() - t0:.3f}\n{outcome}\n")
-            win.close()
+                    f.write(f"mode={cg.mode}\n")
+            _close_after_fault(win)
         finally:
-            dist.destroy_process_group()
+            pass
         return
     if os.environ.get("P2P_TEST_MODE") == "lost_peer":
         # fault injection: rank 1 maps its window and then never takes part in the solve
@@ -168,18 +181,19 @@ def main():
                 eng.bind(b, x, d, r, q)
                 cg = SlabCG(eng, SlabPartition(14, 2, 0), d, dist, window=win)
                 t0 = _t.perf_counter()
-                cg.begin(1e-9)
-                cg.iterate(8)
                 try:
+                    cg.begin(1e-9)            # (collective fallback, e.g. MFS_FUSE_D=0: the bounded all-reduce raises here)
+                    cg.iterate(8)
                     eng.poll()
                     outcome = "no error"
                 except _lib.MfsError as exc:
                     outcome = "MfsError: " + str(exc)
                 with open(f"{out}.rank0.txt", "w") as f:
                     f.write(f"{_t.perf_counter() - t0:.3f}\n{outcome}\n")
-            win.close()
+                    f.write(f"mode={cg.mode}\n")
+            _close_after_fault(win)
         finally:
-            dist.destroy_process_group()
+            pass
         return
     if os.environ.get("P2P_TEST_MODE") == "density":
         try:

@@ -136,3 +136,18 @@ def test_slab_viscosity_cg_matches_reference_golden(name, world):
             np.testing.assert_allclose(arr, g[n], rtol=0, atol=(1e-10 if k == "x" else 1e-13) * scale, err_msg=n)
     assert int(outs[0]["iters"]) == int(g["iters"])
     np.testing.assert_allclose(outs[0]["hist"], g["history"], rtol=1e-9)
+
+
+def test_collective_loop_reports_a_lost_peer():
+    """the "rccl"-style loop of SlabCG (every configuration that cannot take the window loop lands on it): a peer
+    that never joins the solve must surface as MfsTimeout -- status MFS_E_TIMEOUT like the window loop -- within
+    MFS_COLLECTIVE_TIMEOUT_S, not as a rank blocked in all_reduce (round-1 record: gpurun_out/suite_nofuse.log)."""
+    gres = (14, 8, 10)
+    gl, _ = _global_problem(gres, seed=13, all_fluid=True)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "problem.npz")
+        np.savez(path, **gl)
+        mp.spawn(dist_worker.run_lost_peer, args=(2, _free_port(), path, 2.0), nprocs=2, join=True)
+        secs, outcome = open(path + ".rank0.txt").read().strip().split("\n")
+    assert outcome.startswith("MfsTimeout") and "status -4" in outcome and "timed out" in outcome, outcome
+    assert float(secs) < 15.0, secs

@@ -159,13 +159,17 @@ def test_slab_solver_class_rccl_style_loop_over_gloo(tmp_path):
     np.testing.assert_allclose(res[0]["hist"], g["history"], rtol=1e-9)
 
 
-@pytest.mark.parametrize("mode", ["lost_peer", "lost_peer_viscosity"])
-def test_lost_peer_is_reported_not_hung(mode, tmp_path):
+@pytest.mark.parametrize("mode,extra", [("lost_peer", {}), ("lost_peer_viscosity", {}),
+                                        ("lost_peer", {"MFS_FUSE_D": "0"})])
+def test_lost_peer_is_reported_not_hung(mode, extra, tmp_path):
     """fault injection (pressure and viscosity window loops): the neighbour never joins the solve -> every wait gives up
-    after MFS_P2P_TIMEOUT_MS, later kernels return at their top, and the next poll raises with status MFS_E_TIMEOUT (-4)."""
+    after MFS_P2P_TIMEOUT_MS, later kernels return at their top, and the next poll raises with status MFS_E_TIMEOUT (-4).
+    Third case: with the fused direction update off the engine cannot take the window loop and SlabCG falls back to the
+    collective loop (the configuration of round 1's stuck run, gpurun_out/suite_nofuse.log): its bounded waits must
+    report the same status within MFS_COLLECTIVE_TIMEOUT_S."""
     port = _free_port()
     out = str(tmp_path / "lost")
-    env = dict(os.environ, MFS_P2P_TIMEOUT_MS="400", P2P_TEST_MODE=mode)
+    env = dict(os.environ, MFS_P2P_TIMEOUT_MS="400", MFS_COLLECTIVE_TIMEOUT_S="3", P2P_TEST_MODE=mode, **extra)
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), "2", str(port), "-", out, "f64"], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     try:
@@ -175,6 +179,7 @@ def test_lost_peer_is_reported_not_hung(mode, tmp_path):
             q.kill()
         raise
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
-    secs, outcome = open(out + ".rank0.txt").read().strip().split("\n")
+    secs, outcome, mode_line = open(out + ".rank0.txt").read().strip().split("\n")
     assert outcome.startswith("MfsError") and "status -4" in outcome and "timed out" in outcome, outcome
     assert float(secs) < 20.0
+    assert mode_line == ("mode=rccl" if extra else "mode=p2p"), mode_line      # the downgrade is visible
