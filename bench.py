@@ -92,8 +92,26 @@ def cpu_baseline(args, gres, scene_seed):
             "sample": sample, "iters_per_s": iters / dt, "host_cpus": os.cpu_count()}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks as child processes
+    (one per GPU, `python -m torch.distributed.run`), relay their output -- rank 0 prints the JSON line -- and return
+    their exit code.  Done before anything in this process touches the GPU (never an exec of a process that has)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and the HIP-IPC windows need it on this pool
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -101,8 +119,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     # MFS_BENCH_SHARED_GPU=1: REHEARSAL of the N > 1 flow on a one-GPU box -- every rank on cuda:0, gloo instead
     # of RCCL (which refuses two ranks on one device).  The numbers mean nothing; the code path is the real one.
@@ -114,10 +130,11 @@ def main():
     if world > 1 or args.force_phases or args.force_p2p:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        from mfs.dist import pg_timeout       # bounded: a lost rank must end the run, not hang it
         if shared:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout())
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout())
 
     from mfs import _lib, scenes
     from mfs.pcg import PcgEngine

@@ -218,6 +218,11 @@ k_pcg_classify(const T* __restrict__ diag, const T* __restrict__ cx, const T* __
       bool z0 = true, r1 = k[0] == (T)6;
 #pragma unroll
       for (int q = 0; q < 7; ++q) { z0 = z0 && k[q] == (T)0; if (q) r1 = r1 && k[q] == (T)1; }
+      // Asymmetric operator: cz[c] of the vector's FIRST cell is no coefficient of this vector at all -- it is the +z
+      // weight of the last cell of the vector to the left, which takes it from this lane's registers (czr in the
+      // march).  The class constant must therefore stand for it too.  (Symmetric operator: it is k[5], covered.
+      // Found by the 20^3 density golden: a REGULAR vector left of a ZERO one got czr = 0.)
+      if (cz2 && j == 0) { z0 = z0 && cz[c] == (T)0; r1 = r1 && cz[c] == (T)1; }
       all_zero = all_zero && z0;
       all_reg = all_reg && r1;
     }

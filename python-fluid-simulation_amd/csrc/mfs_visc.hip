@@ -229,21 +229,28 @@ k_grid_boundary_condition(G3 g, V3 gv, int vdt, V3 gm, int mdt, const void* sphi
 
 // ------------------------------------------------------------ compact form ---
 // parity class code p = (i&1)<<2 | (j&1)<<1 | (k&1) of a doubled-grid node;
-// class array dims: odd axis -> N, even axis -> N+1; compact index = node >> 1.
+// logical class array dims: odd axis -> N, even axis -> N+1; compact index = node >> 1.
+// Storage: EVERY class array (and mask array) is laid out with the same pitches -- (N[0]+1) planes of py = N[1]+1 rows
+// of pz = N[2]+4 elements -- so that one per-thread offset addresses the same cell in all of them, rows start 16-byte
+// aligned whenever N[2] % 4 == 0 (the (N+1)-long rows of the even-z classes would otherwise break vector alignment on
+// every row, SURVEY.md 7 "hard parts"), and the z-1 / z+VEC neighbours of any vector are addressable.  Pads are 0.
 struct Compact {
   const void* vol[8];           // state dtype; [0] (e,e,e) unused
   const unsigned char* msk[8];  // only the three face classes 3 (e,o,o), 5 (o,e,o), 6 (o,o,e)
   int N[3];
+  int py, pz;                   // row / element pitch (see above)
   __host__ __device__ int dim(int p, int ax) const { return N[ax] + (((p >> (2 - ax)) & 1) ? 0 : 1); }
-  __host__ __device__ int64_t count(int p) const { return (int64_t)dim(p, 0) * dim(p, 1) * dim(p, 2); }
+  __host__ __device__ int64_t idx(int x, int y, int z) const { return ((int64_t)x * py + y) * pz + z; }
+  __host__ __device__ int64_t plane() const { return (int64_t)py * pz; }
+  __host__ __device__ int64_t stored() const { return (int64_t)(N[0] + 1) * py * pz; }   // elements of one array
 };
 __host__ __device__ constexpr int face_class(int comp) { return comp == 0 ? 3 : (comp == 1 ? 5 : 6); }
 __host__ __device__ constexpr int fdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_vcg_setup(int Nx, int Ny, int Nz, const void* sphi, int sdt, const void* vol, int voldt, T* o1, T* o2, T* o3, T* o4,
-            T* o5, T* o6, T* o7, unsigned char* m3, unsigned char* m5, unsigned char* m6) {
+k_vcg_setup(int Nx, int Ny, int Nz, int py, int pz, const void* sphi, int sdt, const void* vol, int voldt, T* o1, T* o2,
+            T* o3, T* o4, T* o5, T* o6, T* o7, unsigned char* m3, unsigned char* m5, unsigned char* m6) {
   const int d1 = 2 * Ny + 1, d2 = 2 * Nz + 1;
   const int64_t n = (int64_t)(2 * Nx + 1) * d1 * d2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,8 +258,7 @@ k_vcg_setup(int Nx, int Ny, int Nz, const void* sphi, int sdt, const void* vol, 
   const int k = (int)(i % d2), j = (int)((i / d2) % d1), ii = (int)(i / ((int64_t)d2 * d1));
   const int p = ((ii & 1) << 2) | ((j & 1) << 1) | (k & 1);
   if (p == 0) return;
-  const int e1 = Ny + ((j & 1) ? 0 : 1), e2 = Nz + ((k & 1) ? 0 : 1);
-  const int64_t ci = ((int64_t)(ii >> 1) * e1 + (j >> 1)) * e2 + (k >> 1);
+  const int64_t ci = ((int64_t)(ii >> 1) * py + (j >> 1)) * pz + (k >> 1);
   T* dst = p == 1 ? o1 : p == 2 ? o2 : p == 3 ? o3 : p == 4 ? o4 : p == 5 ? o5 : p == 6 ? o6 : o7;
   dst[ci] = (T)ldx(vol, voldt, i);
   if (p == 3 || p == 5 || p == 6) {
@@ -310,8 +316,7 @@ struct GlobalSampler {
   const Vec3T<T>& v;
   int x, y, z;
   __device__ __forceinline__ double vol(int p, int ox, int oy, int oz) const {
-    const int e1 = c.N[1] + ((p & 2) ? 0 : 1), e2 = c.N[2] + ((p & 1) ? 0 : 1);
-    return (double)((const T*)c.vol[p])[((int64_t)(x + ox) * e1 + (y + oy)) * e2 + (z + oz)];
+    return (double)((const T*)c.vol[p])[c.idx(x + ox, y + oy, z + oz)];
   }
   __device__ __forceinline__ int64_t fidx(int comp, int dx, int dy, int dz) const {
     const int cs1 = c.N[1] + (comp == 1), cs2 = c.N[2] + (comp == 2);
@@ -321,7 +326,7 @@ struct GlobalSampler {
     return (double)v.p[comp][fidx(comp, dx, dy, dz)];
   }
   __device__ __forceinline__ bool tap_ok(int comp, int dx, int dy, int dz) const {
-    return c.msk[face_class(comp)][fidx(comp, dx, dy, dz)] != 0;
+    return c.msk[face_class(comp)][c.idx(x + dx, y + dy, z + dz)] != 0;
   }
 };
 
@@ -329,7 +334,7 @@ template <typename T, int AXIS, bool MASK>
 __device__ __forceinline__ double vcg_row(const Compact& c, double k1, double k2, const Vec3T<T>& v, int x, int y,
                                           int z, double& own_out) {
   const GlobalSampler<T> smp{c, v, x, y, z};
-  const bool own_ok = c.msk[face_class(AXIS)][smp.fidx(AXIS, 0, 0, 0)] != 0;
+  const bool own_ok = c.msk[face_class(AXIS)][c.idx(x, y, z)] != 0;
   return vcg_row_s<AXIS, MASK>(smp, k1, k2, own_ok, own_out);
 }
 
@@ -540,7 +545,13 @@ k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
 #pragma unroll
   for (int a = 0; a < 3; ++a) { ap[a] = v.p[a]; d1[a] = Ny + (a == 1); d2[a] = Nz + (a == 2); }
 #pragma unroll
-  for (int p = 1; p < 8; ++p) { ap[2 + p] = (const T*)c.vol[p]; d1[2 + p] = c.dim(p, 1); d2[2 + p] = c.dim(p, 2); }
+  int q1[V::NARR], q2[V::NARR];                               // storage pitches (rows per plane, elements per row)
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { q1[a] = d1[a]; q2[a] = d2[a]; }
+#pragma unroll
+  for (int p = 1; p < 8; ++p) {
+    ap[2 + p] = (const T*)c.vol[p]; d1[2 + p] = c.dim(p, 1); d2[2 + p] = c.dim(p, 2); q1[2 + p] = c.py; q2[2 + p] = c.pz;
+  }
   // staging slots of this thread: tile element e = tid + k * BLOCK  <->  (y0 - 1 + e / PZ, z0 - 1 + e % PZ)
   int se[V::NSTG], sgy[V::NSTG], sgz[V::NSTG];
 #pragma unroll
@@ -559,7 +570,7 @@ k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
         const bool ok = se[k] < V::PLANE && sgy[k] < d1[a] && sgz[k] < d2[a];
         // clamped address, unconditional load: the prefetch stays free of control flow
         const int gy = min(sgy[k], d1[a] - 1), gz = min(sgz[k], d2[a] - 1);
-        const T val = ap[a][((int64_t)X * d1[a] + gy) * d2[a] + gz];
+        const T val = ap[a][((int64_t)X * q1[a] + gy) * q2[a] + gz];
         stg[a][k] = ok ? val : (T)0;
       }
     }
@@ -586,8 +597,9 @@ k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     if (more) stage_load(x + 2);                               // in flight while this plane is computed
     const int64_t f0 = ((int64_t)x * Ny + y) * Nz + z, f1 = ((int64_t)x * (Ny + 1) + y) * Nz + z,
                   f2 = ((int64_t)x * Ny + y) * (Nz + 1) + z;
-    const bool ok0 = c.msk[face_class(0)][f0] != 0, ok1 = c.msk[face_class(1)][f1] != 0,
-               ok2 = c.msk[face_class(2)][f2] != 0;
+    const int64_t fm = c.idx(x, y, z);
+    const bool ok0 = c.msk[face_class(0)][fm] != 0, ok1 = c.msk[face_class(1)][fm] != 0,
+               ok2 = c.msk[face_class(2)][fm] != 0;
     double o0, o1, o2;
     const double r0 = vcg_row_s<0, false>(smp, k1, k2, ok0, o0);
     const double r1 = vcg_row_s<1, false>(smp, k1, k2, ok1, o1);
@@ -613,6 +625,8 @@ k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
 
 }  // namespace mfs
 
+#include "mfs_vcg_march.h"
+
 using namespace mfs;
 
 struct mfs_vcg3d {
@@ -633,13 +647,14 @@ struct mfs_vcg3d {
   int split_x;     // 1: the x update rides in the direction-update kernel (default)
   int skip_top_x;  // slab decomposition: the u row at x = Nx-1 belongs to the right neighbour (a ghost here)
   int merge_slabs; // 1 / 0: the fused box and the boundary slabs in one launch (default) / two
+  int march;       // 1 (default): CG applies run the x-marching vector kernel (mfs_vcg_march.h) where the grid allows it
+  int march_bpc;   // its workgroups per CU (2: what its register budget makes resident)
   mfs_p2p* p2p;    // window transport of the slab loop (mfs_vcg3d_attach_p2p); null: the caller moves halos / scalars
 };
 
-static int64_t class_count(const int64_t gres[3], int p) {
-  int64_t n = 1;
-  for (int ax = 0; ax < 3; ++ax) n *= gres[ax] + (((p >> (2 - ax)) & 1) ? 0 : 1);
-  return n;
+// elements one class / mask array occupies (uniform pitches, see struct Compact)
+static int64_t class_count(const int64_t gres[3], int /*p*/) {
+  return (gres[0] + 1) * (gres[1] + 1) * (gres[2] + 4);
 }
 
 static int check_gres(const int64_t gres[3]) {
@@ -686,6 +701,20 @@ static int vslab_grid(const Box3& b) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(256, (n + 255) / 256));
 }
 
+// can the x-marching vector kernel serve this engine / these operands?  (rows of whole 16-byte vectors, 16-byte aligned
+// vectors, one halo vector per thread, both plane buffers within the default 64 KB of dynamic LDS)
+template <typename T>
+static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
+  constexpr int VEC = VecOf<T>::N;
+  const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
+  if (!h->march || Nx < 3 || Ny < 3 || Nz % VEC != 0 || Nz < 2 * VEC) return false;
+  if (2 * (Nz / VEC + 1) > kVmBlock) return false;
+  if ((size_t)2 * vm_buf_elems<VEC>(Nz) * sizeof(T) > 64 * 1024) return false;
+  if (((uintptr_t)v % 16) != 0 || ((uintptr_t)out % 16) != 0) return false;
+  if ((int64_t)(Ny + 1) * (Nz + 4) > (int64_t)0x7fffffff / 2) return false;     // 32-bit in-plane offsets
+  return true;
+}
+
 template <typename T, bool MASK>
 static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial, const double* done, hipStream_t st,
                         int* nparts) {
@@ -694,6 +723,21 @@ static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial,
   Vec3T<T> vv{{vb + h->off[0], vb + h->off[1], vb + h->off[2]}};
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   int used = 0;
+  if (!MASK && !h->tiled && vcg_march_ok<T>(h, v, out)) {
+    constexpr int VEC = VecOf<T>::N;
+    const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + kVmBlock - 1) / kVmBlock;
+    const int64_t total = (int64_t)tiles * (Nx - 2);
+    const int gmain = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * h->march_bpc));
+    const Box3 b0 = vslab_box(h, 0), b1 = vslab_box(h, 1), b2 = vslab_box(h, 2);
+    const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
+    const size_t lds = (size_t)2 * vm_buf_elems<VEC>(Nz) * sizeof(T);
+    hipLaunchKernelGGL((k_vcg_apply_march<T, VEC>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
+                       h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial,
+                       done);
+    MFS_LAUNCH_CHECK();
+    *nparts = gmain + g0 + g1 + g2;
+    return MFS_OK;
+  }
   // (1) the box where all three rows are interior faces: one fused launch
   if (Nx >= 3 && Ny >= 3 && Nz >= 3) {
     const int nbz = (Nz - 2 + 63) / 64, nby = (Ny - 2 + 3) / 4;
@@ -1068,6 +1112,8 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   char* p = core_carve(h->c, h->ws);
   p = (char*)align_up((uintptr_t)p, 4096);
   for (int a = 0; a < 3; ++a) h->cp.N[a] = h->g.N[a];
+  h->cp.py = h->g.N[1] + 1;
+  h->cp.pz = h->g.N[2] + 4;
   h->cp.vol[0] = nullptr;
   for (int q = 0; q < 8; ++q) h->cp.msk[q] = nullptr;
   for (int q = 1; q < 8; ++q) { h->cp.vol[q] = p; p += align_up((size_t)class_count(gres, q) * h->c.elt, 4096) + 4096; }
@@ -1081,6 +1127,8 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->skip_top_x = 0;
   h->p2p = nullptr;
   h->merge_slabs = env_int("MFS_VISC_MERGE", 1);
+  h->march = env_int("MFS_VISC_MARCH", 1);
+  h->march_bpc = std::max(1, env_int("MFS_VISC_MARCH_BPC", 2));
   h->xchunk_tiled = std::max(1, env_int("MFS_VISC_XCHUNK", 32));
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
@@ -1109,12 +1157,12 @@ int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int
   unsigned char *m3 = (unsigned char*)h->cp.msk[3], *m5 = (unsigned char*)h->cp.msk[5], *m6 = (unsigned char*)h->cp.msk[6];
   void* const* v = (void* const*)h->cp.vol;
   if (h->dt == MFS_F32)
-    hipLaunchKernelGGL((k_vcg_setup<float>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, sphi,
-                       sphi_dt, vol, vol_dt, (float*)v[1], (float*)v[2], (float*)v[3], (float*)v[4], (float*)v[5],
+    hipLaunchKernelGGL((k_vcg_setup<float>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, h->cp.py,
+                       h->cp.pz, sphi, sphi_dt, vol, vol_dt, (float*)v[1], (float*)v[2], (float*)v[3], (float*)v[4], (float*)v[5],
                        (float*)v[6], (float*)v[7], m3, m5, m6);
   else
-    hipLaunchKernelGGL((k_vcg_setup<double>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, sphi,
-                       sphi_dt, vol, vol_dt, (double*)v[1], (double*)v[2], (double*)v[3], (double*)v[4],
+    hipLaunchKernelGGL((k_vcg_setup<double>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, h->cp.py,
+                       h->cp.pz, sphi, sphi_dt, vol, vol_dt, (double*)v[1], (double*)v[2], (double*)v[3], (double*)v[4],
                        (double*)v[5], (double*)v[6], (double*)v[7], m3, m5, m6);
   MFS_LAUNCH_CHECK();
   h->k1 = scale * mu;          // `scale * mu * ...`      (left to right, as the reference evaluates it)

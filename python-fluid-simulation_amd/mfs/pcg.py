@@ -131,6 +131,12 @@ class PcgEngine:
         return dict(iterations=it.value, done=bool(done.value), delta=delta.value, alpha=alpha.value,
                     beta=beta.value)
 
+    def poll_raw(self):
+        """the scalar block as it stands, WITHOUT raising on the loop's error word (diagnostics after a failed solve)"""
+        s = self.scalars.cpu()
+        return dict(iterations=int(s[_lib.S_ITERS]), done=bool(s[_lib.S_DONE] != 0), delta=float(s[_lib.S_LASTRR]),
+                    err=int(s[_lib.S_ERR]))
+
     def solve(self, tol, max_iter, check_every=32):
         it = C.c_int64()
         st = _lib.check(self.lib.mfs_pcg3d_solve(self.h, float(tol), int(max_iter), int(check_every), T.stream(),
