@@ -300,6 +300,11 @@ int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters_host, int* do
 int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every,
                     mfs_stream stream, int64_t* iters_host);
 int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream);
+/* Which kernel the CG applies (matvecmul_{x,y,z}_kernel, ViscosityCGSolver3D.py:248-456, on the direction vector)
+ * take for the engine as bound: 2 = x-marching 16-byte-vector kernel (csrc/mfs_vcg_march.h; needs Nz % 4 == 0 (fp32) /
+ * Nz % 2 == 0 (fp64) and 16-byte aligned vectors), 1 = LDS-tiled one-cell-per-lane kernel (MFS_VISC_TILED=1),
+ * 0 = one-cell-per-lane direct-load kernel.  All three give bit-identical results.                              */
+int mfs_vcg3d_apply_kernel(mfs_vcg3d* h);
 /* Slab decomposition along x (the build's extension; host driver mfs/dist.py:SlabVCG): one
  * iteration = halo exchange of d's edge planes (3 components), phase_apply, phase_reduce(0), all-reduce of
  * scalars[MFS_PCG_S_DQ], phase_update_xr, phase_reduce(1), all-reduce of scalars[MFS_PCG_S_RR], phase_update_d

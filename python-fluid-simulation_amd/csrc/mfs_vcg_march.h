@@ -32,6 +32,10 @@
 #define MFS_VMARCH_MIN_WAVES 2     // waves per SIMD the kernel is compiled for (256 VGPRs)
 #endif
 
+#ifndef MFS_VM_CELL_GROUP
+#define MFS_VM_CELL_GROUP 0     // cells of a vector whose accumulation chains are interleaved (0: all of them)
+#endif
+
 namespace mfs {
 
 constexpr int kVmBlock = 256;
@@ -56,6 +60,33 @@ __device__ __forceinline__ void vstore_u(T* p, vec_t<T, VEC> v) {
   *reinterpret_cast<typename UVecT<T, VEC>::type*>(p) = u;
 }
 
+// lane l receives lane l-1's / l+1's value (lane 0 / 63 keep their own): the z-1 / z+VEC neighbour of a vector is an
+// element of the neighbouring lane's vector -- one DPP move instead of a 4-byte load that drags in a whole line
+template <typename T>
+__device__ __forceinline__ T vm_from_left(T v) {
+  if (sizeof(T) == 4) {
+    const int i = __builtin_bit_cast(int, (float)v);
+    return (T)__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+  }
+  const long long d = __builtin_bit_cast(long long, (double)v);
+  const int lo = (int)d, hi = (int)(d >> 32);
+  const unsigned rlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  const unsigned rhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return (T)__builtin_bit_cast(double, ((long long)rhi << 32) | rlo);
+}
+template <typename T>
+__device__ __forceinline__ T vm_from_right(T v) {
+  if (sizeof(T) == 4) {
+    const int i = __builtin_bit_cast(int, (float)v);
+    return (T)__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+  }
+  const long long d = __builtin_bit_cast(long long, (double)v);
+  const int lo = (int)d, hi = (int)(d >> 32);
+  const unsigned rlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  const unsigned rhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return (T)__builtin_bit_cast(double, ((long long)rhi << 32) | rlo);
+}
+
 // The operands of one step, in registers.  vcg_row_s asks for samples by (array, offset); every request below is
 // resolved at compile time (J and the tap table entries are constants after unrolling) to one register element.
 template <typename T, int VEC>
@@ -75,14 +106,16 @@ struct VmRegs {
   T czl, exzzr, eyzzr;          // C[x,y,z0-1], EXZ[x,y,z0+VEC], EYZ[x,y,z0+VEC]
 };
 
-template <typename T, int VEC, int J>
+template <typename T, int VEC>
 struct VmSampler {
   const VmRegs<T, VEC>& r;
+  int j0;        // the sampler's cell j is cell j0 + j of the vector
   // element J+1 / J-1 of the own-row vector `a`, with the neighbours' cells at the ends
-  static __device__ __forceinline__ T zp(const vec_t<T, VEC>& a, T right) { return J < VEC - 1 ? a[J < VEC - 1 ? J + 1 : J] : right; }
-  static __device__ __forceinline__ T zm(const vec_t<T, VEC>& a, T left) { return J > 0 ? a[J > 0 ? J - 1 : J] : left; }
+  static __device__ __forceinline__ T zp(const vec_t<T, VEC>& a, T right, int J) { return J < VEC - 1 ? a[J < VEC - 1 ? J + 1 : J] : right; }
+  static __device__ __forceinline__ T zm(const vec_t<T, VEC>& a, T left, int J) { return J > 0 ? a[J > 0 ? J - 1 : J] : left; }
 
-  __device__ __forceinline__ double vel(int comp, int dx, int dy, int dz) const {
+  __device__ __forceinline__ double vel(int jj, int comp, int dx, int dy, int dz) const {
+    const int J = j0 + jj;
     const int key = comp * 27 + (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
     switch (key) {
       // ---- u
@@ -91,35 +124,36 @@ struct VmSampler {
       case 0 * 27 + 0 * 9 + 1 * 3 + 1: return (double)r.um[J];
       case 0 * 27 + 1 * 9 + 2 * 3 + 1: return (double)r.uyp[J];
       case 0 * 27 + 1 * 9 + 0 * 3 + 1: return (double)r.uym[J];
-      case 0 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.uc, r.uzr);
-      case 0 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.uc, r.uzl);
+      case 0 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.uc, r.uzr, J);
+      case 0 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.uc, r.uzl, J);
       case 0 * 27 + 2 * 9 + 0 * 3 + 1: return (double)r.upym[J];
-      case 0 * 27 + 2 * 9 + 1 * 3 + 0: return (double)zm(r.up, r.upzl);
+      case 0 * 27 + 2 * 9 + 1 * 3 + 0: return (double)zm(r.up, r.upzl, J);
       // ---- v
       case 1 * 27 + 1 * 9 + 1 * 3 + 1: return (double)r.vc[J];
       case 1 * 27 + 2 * 9 + 1 * 3 + 1: return (double)r.vp[J];
       case 1 * 27 + 0 * 9 + 1 * 3 + 1: return (double)r.vm[J];
       case 1 * 27 + 1 * 9 + 2 * 3 + 1: return (double)r.vyp[J];
       case 1 * 27 + 1 * 9 + 0 * 3 + 1: return (double)r.vym[J];
-      case 1 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.vc, r.vzr);
-      case 1 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.vc, r.vzl);
+      case 1 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.vc, r.vzr, J);
+      case 1 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.vc, r.vzl, J);
       case 1 * 27 + 0 * 9 + 2 * 3 + 1: return (double)r.vmyp[J];
-      case 1 * 27 + 1 * 9 + 2 * 3 + 0: return (double)zm(r.vyp, r.vypzl);
+      case 1 * 27 + 1 * 9 + 2 * 3 + 0: return (double)zm(r.vyp, r.vypzl, J);
       // ---- w
       case 2 * 27 + 1 * 9 + 1 * 3 + 1: return (double)r.wc[J];
       case 2 * 27 + 2 * 9 + 1 * 3 + 1: return (double)r.wp[J];
       case 2 * 27 + 0 * 9 + 1 * 3 + 1: return (double)r.wm[J];
       case 2 * 27 + 1 * 9 + 2 * 3 + 1: return (double)r.wyp[J];
       case 2 * 27 + 1 * 9 + 0 * 3 + 1: return (double)r.wym[J];
-      case 2 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.wc, r.wzr);
-      case 2 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.wc, r.wzl);
-      case 2 * 27 + 0 * 9 + 1 * 3 + 2: return (double)zp(r.wm, r.wmzr);
+      case 2 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.wc, r.wzr, J);
+      case 2 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.wc, r.wzl, J);
+      case 2 * 27 + 0 * 9 + 1 * 3 + 2: return (double)zp(r.wm, r.wmzr, J);
       case 2 * 27 + 1 * 9 + 0 * 3 + 2: return (double)r.wym[J + 1];
     }
     __builtin_trap();            // a tap the register file does not hold: the tap table and this kernel disagree
   }
 
-  __device__ __forceinline__ double vol(int p, int ox, int oy, int oz) const {
+  __device__ __forceinline__ double vol(int jj, int p, int ox, int oy, int oz) const {
+    const int J = j0 + jj;
     const int key = p * 27 + (ox + 1) * 9 + (oy + 1) * 3 + (oz + 1);
     switch (key) {
       case 3 * 27 + 13: return (double)r.fx[J];
@@ -128,47 +162,46 @@ struct VmSampler {
       case 7 * 27 + 13: return (double)r.cc[J];
       case 7 * 27 + 0 * 9 + 1 * 3 + 1: return (double)r.cm[J];
       case 7 * 27 + 1 * 9 + 0 * 3 + 1: return (double)r.cym[J];
-      case 7 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.cc, r.czl);
+      case 7 * 27 + 1 * 9 + 1 * 3 + 0: return (double)zm(r.cc, r.czl, J);
       case 1 * 27 + 13: return (double)r.exyc[J];
       case 1 * 27 + 2 * 9 + 1 * 3 + 1: return (double)r.exyp[J];
       case 1 * 27 + 1 * 9 + 2 * 3 + 1: return (double)r.exyyp[J];
       case 2 * 27 + 13: return (double)r.exzc[J];
       case 2 * 27 + 2 * 9 + 1 * 3 + 1: return (double)r.exzp[J];
-      case 2 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.exzc, r.exzzr);
+      case 2 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.exzc, r.exzzr, J);
       case 4 * 27 + 13: return (double)r.eyzc[J];
       case 4 * 27 + 1 * 9 + 2 * 3 + 1: return (double)r.eyzyp[J];
-      case 4 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.eyzc, r.eyzzr);
+      case 4 * 27 + 1 * 9 + 1 * 3 + 2: return (double)zp(r.eyzc, r.eyzzr, J);
     }
     __builtin_trap();
   }
-  __device__ __forceinline__ bool tap_ok(int, int, int, int) const { return true; }
+  __device__ __forceinline__ bool tap_ok(int, int, int, int, int) const { return true; }
 };
 
-// the three rows of cell J of the vector
-template <typename T, int VEC, int J>
-__device__ __forceinline__ void vm_cell(const VmRegs<T, VEC>& rg, double k1, double k2, unsigned mu, unsigned mv, unsigned mw,
-                                        vec_t<T, VEC>& ou, vec_t<T, VEC>& ov, vec_t<T, VEC>& ow, double (&own)[3][VEC]) {
-  const VmSampler<T, VEC, J> smp{rg};
-  const bool oku = ((mu >> (8 * J)) & 0xffu) != 0, okv = ((mv >> (8 * J)) & 0xffu) != 0, okw = ((mw >> (8 * J)) & 0xffu) != 0;
-  ou[J] = (T)vcg_row_s<0, false>(smp, k1, k2, oku, own[0][J]);
-  ov[J] = (T)vcg_row_s<1, false>(smp, k1, k2, okv, own[1][J]);
-  ow[J] = (T)vcg_row_s<2, false>(smp, k1, k2, okw, own[2][J]);
-}
-
-template <typename T, int VEC, int J>
-struct VmCells {
-  static __device__ __forceinline__ void run(const VmRegs<T, VEC>& rg, double k1, double k2, unsigned mu, unsigned mv,
-                                             unsigned mw, vec_t<T, VEC>& ou, vec_t<T, VEC>& ov, vec_t<T, VEC>& ow,
-                                             double (&own)[3][VEC]) {
-    vm_cell<T, VEC, J>(rg, k1, k2, mu, mv, mw, ou, ov, ow, own);
-    VmCells<T, VEC, J + 1>::run(rg, k1, k2, mu, mv, mw, ou, ov, ow, own);
+// row AXIS of all cells of the vector, MFS_VM_CELL_GROUP cells at a time (their accumulation chains interleaved:
+// vcg_row_n); own . out joins `acc` unless the cell is one of the row's two array-boundary cells (z = 0 / z = Nz-1:
+// never stored) or the lane is a clamped duplicate (`count` false)
+template <typename T, int VEC, int AXIS>
+__device__ __forceinline__ void vm_row(const VmRegs<T, VEC>& rg, double k1, double k2, unsigned m, vec_t<T, VEC>& q, bool first,
+                                       bool last, bool count, double& acc) {
+  constexpr int NC = (MFS_VM_CELL_GROUP > 0 && MFS_VM_CELL_GROUP < VEC && VEC % MFS_VM_CELL_GROUP == 0) ? MFS_VM_CELL_GROUP : VEC;
+#pragma unroll
+  for (int j0 = 0; j0 < VEC; j0 += NC) {
+    const VmSampler<T, VEC> smp{rg, j0};
+    bool ok[NC];
+    double out[NC], own[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) ok[j] = ((m >> (8 * (j0 + j) + AXIS)) & 1u) != 0;     // byte J of m: cell J; bit AXIS: this row
+    vcg_row_n<AXIS, false, NC>(smp, k1, k2, ok, out, own);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int J = j0 + j;
+      q[J] = (T)out[j];
+      const bool bnd = (J == 0 && first) || (J == VEC - 1 && last);
+      if (count && !bnd) acc += own[j] * (double)q[J];
+    }
   }
-};
-template <typename T, int VEC>
-struct VmCells<T, VEC, VEC> {
-  static __device__ __forceinline__ void run(const VmRegs<T, VEC>&, double, double, unsigned, unsigned, unsigned,
-                                             vec_t<T, VEC>&, vec_t<T, VEC>&, vec_t<T, VEC>&, double (&)[3][VEC]) {}
-};
+}
 
 // VEC mask bytes at a VEC-aligned byte offset, as an unsigned (byte J = cell J)
 template <int VEC>
@@ -179,33 +212,45 @@ __device__ __forceinline__ unsigned vm_mask(const unsigned char* p) {
 }
 
 // store the computed cells of one component's vector (the z = 0 / z = Nz-1 cells of a row are array-boundary faces:
-// never written) and accumulate own . out over them
+// never written)
 template <typename T, int VEC, bool ALIGNED>
-__device__ __forceinline__ void vm_store(T* p, vec_t<T, VEC> o, const double (&own)[VEC], bool first, bool last, double& acc) {
+__device__ __forceinline__ void vm_store(T* p, vec_t<T, VEC> o, bool first, bool last) {
   if (!first && !last) {
     if (ALIGNED) vstore<T, VEC>(p, o); else vstore_u<T, VEC>(p, o);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc += own[j] * (double)o[j];
   } else {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const bool bnd = (first && j == 0) || (last && j == VEC - 1);
-      if (!bnd) { p[j] = o[j]; acc += own[j] * (double)o[j]; }
+      if (!bnd) p[j] = o[j];
     }
   }
 }
 
-// element counts of one LDS plane buffer (u image, v image, w image)
+// LDS: a ring of kVmRing plane slots (planes x-1, x, x+1 being read, x+2 being written), each the three components'
+// images [Nz halo | tile | Nz halo]
+constexpr int kVmRing = 4;
 template <int VEC>
 __host__ __device__ inline int vm_su(int Nz) { return 2 * Nz + kVmBlock * VEC; }
-template <int VEC>
-__host__ __device__ inline int vm_sw(int Nz) { return 2 * (Nz + 1) + kVmBlock * VEC + (kVmBlock * VEC) / Nz + 2 + VEC; }
-template <int VEC>
-__host__ __device__ inline int vm_buf_elems(int Nz) { return (2 * vm_su<VEC>(Nz) + vm_sw<VEC>(Nz) + 3) / 4 * 4; }
+template <typename T, int VEC>
+__host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing * 3 * vm_su<VEC>(Nz) * sizeof(T); }
+
+#define MFS_VM_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef MFS_VM_PROBE_NOSCAL     // traffic probe (WRONG results): no z-neighbour scalar loads, no mask loads
+#define MFS_VM_SC(expr) ((T)1)
+#define MFS_VM_MK(expr) 0x01010101u
+#else
+#define MFS_VM_SC(expr) (expr)
+#define MFS_VM_MK(expr) (expr)
+#endif
+#ifdef MFS_VM_PROBE_NONBR      // traffic probe (WRONG results): class-array neighbour rows read as own rows
+#define MFS_VM_NBR(off) 0
+#else
+#define MFS_VM_NBR(off) (off)
+#endif
 
 // slabs: the three boundary slabs (u at x = Nx-1, v at y = Ny-1, w at z = Nz-1) ride as extra blocks, as in k_vcg_apply_all
-template <typename T, int VEC>
-__global__ void __launch_bounds__(kVmBlock, MFS_VMARCH_MIN_WAVES)
+template <typename T, int VEC, int WAVES>
+__global__ void __launch_bounds__(kVmBlock, WAVES)
 k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
                   int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
                   const double* __restrict__ done_flag) {
@@ -239,18 +284,13 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   const T* const U = v.p[0];
   const T* const Vv = v.p[1];
   const T* const W = v.p[2];
+  // the seven class arrays sit at one constant stride in the engine's workspace (and so do the three mask arrays):
+  // one base pointer each instead of ten
   const T* const C1 = (const T*)c.vol[1];
-  const T* const C2 = (const T*)c.vol[2];
-  const T* const C3 = (const T*)c.vol[3];
-  const T* const C4 = (const T*)c.vol[4];
-  const T* const C5 = (const T*)c.vol[5];
-  const T* const C6 = (const T*)c.vol[6];
-  const T* const C7 = (const T*)c.vol[7];
-  const unsigned char* const M3 = c.msk[3];
-  const unsigned char* const M5 = c.msk[5];
-  const unsigned char* const M6 = c.msk[6];
+  const int64_t cs = (const T*)c.vol[2] - (const T*)c.vol[1];
+  const unsigned char* const MP = c.msk;
   const int tid = threadIdx.x;
-  const int SU = vm_su<VEC>(Nz), BUF = vm_buf_elems<VEC>(Nz);
+  const int SU = vm_su<VEC>(Nz), BUF = 3 * SU;
   const int tile_elems = kVmBlock * VEC;
 
   for (int64_t i = s0; i < s1;) {
@@ -269,135 +309,159 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     const int o_uv = y * Nz + z0, o_w = y * W1 + z0, o_c = y * c.pz + z0;   // in-plane offsets (u / v, w, class arrays)
     const int tile_items = min(kVmBlock, ipp - tile * kVmBlock);
     const int tile_len = tile_items * VEC;
-    const int yy0 = (tile * kVmBlock) / nzv, zv0 = tile * kVmBlock - yy0 * nzv;
-    const int yyl = (tile * kVmBlock + tile_items - 1) / nzv;
-    const int m0 = Nz + tile * tile_elems;                   // in-plane offset of the tile's first u / v vector
-    const int m0w = (yy0 + 1) * W1 + zv0 * VEC;              // ... of its first w vector
-    const int tile_len_w = tile_len + (yyl - yy0);           // the w tile spans one more element per row crossed
-    // LDS offsets of this thread's vectors inside a plane buffer (images mirror memory: [halo row | tile | halo row])
+    const int m0 = Nz + tile * tile_elems;                   // in-plane (u-layout) offset of the tile's first vector
+    // LDS offset of this thread's vectors inside an image.  All three images use the u layout -- rows of Nz elements,
+    // [Nz halo | tile | Nz halo], mirroring the memory of the u / v components, every access 16-byte aligned.  The w
+    // component's (Nz+1)-th element of a row is not kept: only the row's never-computed last cell would tap it.
     const int lu = Nz + tid * VEC;
-    const int lw = 2 * SU + W1 + tid * VEC + (yy - yy0);
-    // halo ownership.  u, v: the Nz elements below the tile and the Nz above = 2 * nzv aligned vectors, thread t owns
-    // vector t.  w: two rows of Nz+1 elements = 2 * (nzv + 1) unaligned vectors, the last of a row pulled back so that
-    // it ends with the row (it overlaps its predecessor; both write the same values).
+    // halo ownership: the Nz elements below the tile and the Nz above = 2 * nzv vectors, thread t owns vector t
     const bool hact = tid < 2 * nzv;
     const bool hlow = tid < nzv;
-    const int hg = hlow ? m0 - Nz + tid * VEC : m0 + tile_len + (tid - nzv) * VEC;
-    const int hl = hlow ? tid * VEC : Nz + tile_len + (tid - nzv) * VEC;
-    const int nhw = nzv + 1;
-    const bool hwact = tid < 2 * nhw;
-    const bool hwlow = tid < nhw;
-    const int hwk = min((hwlow ? tid : tid - nhw) * VEC, W1 - VEC);
-    const int hgw = hwlow ? m0w - W1 + hwk : m0w + tile_len_w + hwk;
-    const int hlw = 2 * SU + (hwlow ? hwk : W1 + tile_len_w + hwk);
+    const int hg = hlow ? m0 - Nz + tid * VEC : m0 + tile_len + (tid - nzv) * VEC;     // in-plane, u / v
+    const int hl = hlow ? tid * VEC : Nz + tile_len + (tid - nzv) * VEC;               // in the image
+    const int hgw = hg + hg / Nz;                                                     // in-plane, w (rows of Nz+1)
+
+    // one plane's own vectors and halo vectors: global -> registers -> its ring slot
+    struct Plane { V u, v, w, hu, hv, hw; };
+    auto fetch = [&](int xp) {
+      Plane p;
+      p.u = vload<T, VEC>(U + (int64_t)xp * su + o_uv);
+      p.v = vload<T, VEC>(Vv + (int64_t)xp * sv + o_uv);
+      p.w = vload_u<T, VEC>(W + (int64_t)xp * sw + o_w);
+      p.hu = V{}; p.hv = V{}; p.hw = V{};
+#ifdef MFS_VM_PROBE_NOHALO     // traffic probe (WRONG results): what do the halo rows cost?
+      if (false) {
+#else
+      if (hact) {
+#endif
+        p.hu = vload<T, VEC>(U + (int64_t)xp * su + hg);
+        p.hv = vload<T, VEC>(Vv + (int64_t)xp * sv + hg);
+        p.hw = vload_u<T, VEC>(W + (int64_t)xp * sw + hgw);
+      }
+      return p;
+    };
+    auto publish = [&](T* b, const Plane& p) {
+      if (active) { vstore<T, VEC>(b + lu, p.u); vstore<T, VEC>(b + SU + lu, p.v); vstore<T, VEC>(b + 2 * SU + lu, p.w); }
+      if (hact) { vstore<T, VEC>(b + hl, p.hu); vstore<T, VEC>(b + SU + hl, p.hv); vstore<T, VEC>(b + 2 * SU + hl, p.hw); }
+    };
+
+    // z neighbours by DPP.  Lane l-1 / l+1 of the wave holds the row's previous / next vector whenever this lane's
+    // vector is not the first / last of its row (then the neighbour is never used); only lane 0 / 63 can have its
+    // neighbour in another wave, and only when a wave's 64 vectors do not start on a row boundary, i.e. 64 % nzv != 0:
+    // those single lanes then read the value themselves (exec-masked: one lane).
+    const bool fix = (64 % nzv) != 0;
+    const bool fixl = fix && (tid & 63) == 0 && !first, fixr = fix && (tid & 63) == 63 && !last;
+    auto ZL = [&](const V& a, const T* at) { T r = vm_from_left<T>(a[VEC - 1]); if (fixl) r = at[-1]; return r; };
+    auto ZR = [&](const V& a, const T* at) { T r = vm_from_right<T>(a[0]); if (fixr) r = at[VEC]; return r; };
 
     VmRegs<T, VEC> rg;
-    // ---- prologue: planes x0-1, x0, x0+1 of the own rows; the carried samples; plane x0's images
+    // ---- prologue: the images of planes x0-1, x0, x0+1 into ring slots 0, 1, 2; the volume samples of the first step
     {
-      const T* const u0 = U + (int64_t)x0 * su;
-      const T* const v0 = Vv + (int64_t)x0 * sv;
-      const T* const w0 = W + (int64_t)x0 * sw;
-      rg.um = vload<T, VEC>(u0 - su + o_uv); rg.uc = vload<T, VEC>(u0 + o_uv); rg.up = vload<T, VEC>(u0 + su + o_uv);
-      rg.vm = vload<T, VEC>(v0 - sv + o_uv); rg.vc = vload<T, VEC>(v0 + o_uv); rg.vp = vload<T, VEC>(v0 + sv + o_uv);
-      rg.wm = vload_u<T, VEC>(w0 - sw + o_w); rg.wc = vload_u<T, VEC>(w0 + o_w); rg.wp = vload_u<T, VEC>(w0 + sw + o_w);
-      rg.wmzr = w0[-sw + o_w + VEC];
-      rg.vmyp = vload<T, VEC>(v0 - sv + o_uv + Nz);
-      rg.cm = vload<T, VEC>(C7 + (int64_t)(x0 - 1) * sc + o_c);
-      rg.exyp = vload<T, VEC>(C1 + (int64_t)x0 * sc + o_c);     // rotated into exyc / exzc at the top of the first step
-      rg.exzp = vload<T, VEC>(C2 + (int64_t)x0 * sc + o_c);
-      T* const b = smem;
-      if (active) {
-        vstore<T, VEC>(b + lu, rg.uc);
-        vstore<T, VEC>(b + SU + lu, rg.vc);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) b[lw + j] = rg.wc[j];
-      }
-      if (hact) {
-        vstore<T, VEC>(b + hl, vload<T, VEC>(u0 + hg));
-        vstore<T, VEC>(b + SU + hl, vload<T, VEC>(v0 + hg));
-      }
-      if (hwact) {
-        const V h = vload_u<T, VEC>(w0 + hgw);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) b[hlw + j] = h[j];
-      }
+      const Plane pa = fetch(x0 - 1), pb = fetch(x0), pc = fetch(x0 + 1);
+      publish(smem, pa); publish(smem + BUF, pb); publish(smem + 2 * BUF, pc);
+      const T* const q = C1 + (int64_t)x0 * sc + o_c;          // class 1 of this vector; class p at q + (p-1)*cs
+      rg.cm = vload<T, VEC>(q + 6 * cs - sc);
+      rg.exyc = vload<T, VEC>(q); rg.exzc = vload<T, VEC>(q + cs);
+      rg.fx = vload<T, VEC>(q + 2 * cs); rg.fy = vload<T, VEC>(q + 4 * cs); rg.fz = vload<T, VEC>(q + 5 * cs);
+      rg.cc = vload<T, VEC>(q + 6 * cs); rg.cym = vload<T, VEC>(q + 6 * cs - MFS_VM_NBR(c.pz));
+      rg.czl = (T)0; rg.exzzr = (T)0; rg.eyzzr = (T)0;
+      if (fixl) rg.czl = q[6 * cs - 1];
+      if (fixr) { rg.exzzr = q[cs + VEC]; rg.eyzzr = q[3 * cs + VEC]; }
+      rg.exyp = vload<T, VEC>(q + sc); rg.exyyp = vload<T, VEC>(q + MFS_VM_NBR(c.pz));
+      rg.exzp = vload<T, VEC>(q + cs + sc);
+      rg.eyzc = vload<T, VEC>(q + 3 * cs); rg.eyzyp = vload<T, VEC>(q + 3 * cs + MFS_VM_NBR(c.pz));
     }
-    // halo vectors of plane x0+1 (published during step x0)
-    V Hu = {}, Hv = {}, Hw = {};
-    {
-      const int xh = min(x0 + 1, Nx - 1);
-      if (hact) { Hu = vload<T, VEC>(U + (int64_t)xh * su + hg); Hv = vload<T, VEC>(Vv + (int64_t)xh * sv + hg); }
-      if (hwact) Hw = vload_u<T, VEC>(W + (int64_t)xh * sw + hgw);
-    }
-    MFS_VISC_LDS_BARRIER();
+    unsigned msk = MFS_VM_MK(vm_mask<VEC>(MP + (int64_t)x0 * sc + o_c));
 
     for (int x = x0; x < x1; ++x) {
-      const int cur = (x - x0) & 1;
-      T* const bc = smem + cur * BUF;
-      T* const bn = smem + (cur ^ 1) * BUF;
-      // ---- (1) prefetch: own rows and halo vectors of plane x+2 (clamped on the last planes: values unused)
-      const int x2 = min(x + 2, Nx - 1);
-      const V un = vload<T, VEC>(U + (int64_t)x2 * su + o_uv);
-      const V vn = vload<T, VEC>(Vv + (int64_t)x2 * sv + o_uv);
-      const V wn = vload_u<T, VEC>(W + (int64_t)x2 * sw + o_w);
-      V hun = {}, hvn = {}, hwn = {};
-      if (hact) { hun = vload<T, VEC>(U + (int64_t)x2 * su + hg); hvn = vload<T, VEC>(Vv + (int64_t)x2 * sv + hg); }
-      if (hwact) hwn = vload_u<T, VEC>(W + (int64_t)x2 * sw + hgw);
-      // ---- (2) this plane's volume samples and masks
-      const int64_t pc = (int64_t)x * sc + o_c;
-      rg.exyc = rg.exyp; rg.exzc = rg.exzp;
-      rg.fx = vload<T, VEC>(C3 + pc); rg.fy = vload<T, VEC>(C5 + pc); rg.fz = vload<T, VEC>(C6 + pc);
-      rg.cc = vload<T, VEC>(C7 + pc); rg.cym = vload<T, VEC>(C7 + pc - c.pz); rg.czl = C7[pc - 1];
-      rg.exyp = vload<T, VEC>(C1 + pc + sc); rg.exyyp = vload<T, VEC>(C1 + pc + c.pz);
-      rg.exzp = vload<T, VEC>(C2 + pc + sc); rg.exzzr = C2[pc + VEC];
-      rg.eyzc = vload<T, VEC>(C4 + pc); rg.eyzyp = vload<T, VEC>(C4 + pc + c.pz); rg.eyzzr = C4[pc + VEC];
-      const unsigned mu = vm_mask<VEC>(M3 + pc), mv = vm_mask<VEC>(M5 + pc), mw = vm_mask<VEC>(M6 + pc);
-      // ---- (3) in-plane neighbours of plane x from its LDS images
-      rg.uyp = vload<T, VEC>(bc + lu + Nz); rg.uym = vload<T, VEC>(bc + lu - Nz);
-      rg.uzl = bc[lu - 1]; rg.uzr = bc[lu + VEC];
-      rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vym = vload<T, VEC>(bc + SU + lu - Nz);
-      rg.vzl = bc[SU + lu - 1]; rg.vzr = bc[SU + lu + VEC]; rg.vypzl = bc[SU + lu + Nz - 1];
-#pragma unroll
-      for (int j = 0; j <= VEC; ++j) rg.wym[j] = bc[lw - W1 + j];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) rg.wyp[j] = bc[lw + W1 + j];
-      rg.wzl = bc[lw - 1]; rg.wzr = bc[lw + VEC];
-      // ---- (4) publish plane x+1's images (always: the last step still needs u of plane x1); one barrier per plane
-      if (active) {
-        vstore<T, VEC>(bn + lu, rg.up);
-        vstore<T, VEC>(bn + SU + lu, rg.vp);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) bn[lw + j] = rg.wp[j];
-      }
-      if (hact) { vstore<T, VEC>(bn + hl, Hu); vstore<T, VEC>(bn + SU + hl, Hv); }
-      if (hwact) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) bn[hlw + j] = Hw[j];
-      }
+      const int k = x - x0;
+      const T* const bm = smem + (k % kVmRing) * BUF;             // plane x-1
+      const T* const bc = smem + ((k + 1) % kVmRing) * BUF;       // plane x
+      const T* const bn = smem + ((k + 2) % kVmRing) * BUF;       // plane x+1
+      T* const bw = smem + ((k + 3) % kVmRing) * BUF;             // plane x+2 (written at the end of this step)
+      // ---- (1) ONE barrier per plane: plane x+1's images (published at the end of the previous step) are complete,
+      //      and nobody reads plane x-2's slot any more (it is written at the end of this step)
       MFS_VISC_LDS_BARRIER();
-      // ---- (5) the two looks into plane x+1 off the own row
-      rg.upym = vload<T, VEC>(bn + lu - Nz);
-      rg.upzl = bn[lu - 1];
-      // ---- (6) the three rows of every cell of the vector
-      V qu, qv, qw;
-      double own[3][VEC];
-      VmCells<T, VEC, 0>::run(rg, k1, k2, mu, mv, mw, qu, qv, qw, own);
-      // ---- (7) stores, d.q
-      if (active) {
-        vm_store<T, VEC, true>(ox + (int64_t)x * su + o_uv, qu, own[0], first, last, acc);
-        vm_store<T, VEC, true>(oy + (int64_t)x * sv + o_uv, qv, own[1], first, last, acc);
-        vm_store<T, VEC, false>(oz + (int64_t)x * sw + o_w, qw, own[2], first, last, acc);
+      // ---- (2) in flight for the whole step: own rows and halo vectors of plane x+2 (clamped at the end: unused)
+      const Plane pn = fetch(min(x + 2, Nx - 1));
+      const T* const qn = C1 + (int64_t)min(x + 1, Nx - 2) * sc + o_c;      // next step's class samples
+      const unsigned char* const mqn = MP + (int64_t)min(x + 1, Nx - 2) * sc + o_c;
+      MFS_VM_PIN();
+      // ---- (3) u rows.  Every velocity operand comes from the images (the ring is the register file of the march:
+      //      nothing velocity is carried across steps); the registers of the class samples only this phase reads take
+      //      the next step's afterwards (a whole step in flight)
+      rg.um = vload<T, VEC>(bm + lu); rg.uc = vload<T, VEC>(bc + lu); rg.up = vload<T, VEC>(bn + lu);
+      rg.uyp = vload<T, VEC>(bc + lu + Nz); rg.uym = vload<T, VEC>(bc + lu - Nz);
+      rg.uzl = ZL(rg.uc, bc + lu); rg.uzr = ZR(rg.uc, bc + lu);
+      rg.vc = vload<T, VEC>(bc + SU + lu); rg.vm = vload<T, VEC>(bm + SU + lu);
+      rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vmyp = vload<T, VEC>(bm + SU + lu + Nz);
+      rg.wc = vload<T, VEC>(bc + 2 * SU + lu); rg.wzr = ZR(rg.wc, bc + 2 * SU + lu);
+      rg.wm = vload<T, VEC>(bm + 2 * SU + lu); rg.wmzr = ZR(rg.wm, bm + 2 * SU + lu);
+      { const T t = vm_from_right<T>(rg.exzc[0]); rg.exzzr = fixr ? rg.exzzr : t; }      // EXZ[x, y, z0+VEC]
+      V qu;
+      vm_row<T, VEC, 0>(rg, k1, k2, msk, qu, first, last, active, acc);
+      if (active) vm_store<T, VEC, true>(ox + (int64_t)x * su + o_uv, qu, first, last);
+      MFS_VM_PIN();
+      const V fxn = vload<T, VEC>(qn + 2 * cs), ccn = vload<T, VEC>(qn + 6 * cs), exyypn = vload<T, VEC>(qn + MFS_VM_NBR(c.pz));
+      T exzzrn = (T)0;
+      if (fixr) exzzrn = qn[cs + VEC];
+      MFS_VM_PIN();
+      // ---- (4) v rows
+      rg.vc = vload<T, VEC>(bc + SU + lu); rg.vp = vload<T, VEC>(bn + SU + lu); rg.vm = vload<T, VEC>(bm + SU + lu);
+      rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vym = vload<T, VEC>(bc + SU + lu - Nz);
+      rg.vzl = ZL(rg.vc, bc + SU + lu); rg.vzr = ZR(rg.vc, bc + SU + lu);
+      rg.up = vload<T, VEC>(bn + lu); rg.upym = vload<T, VEC>(bn + lu - Nz);
+      rg.uc = vload<T, VEC>(bc + lu); rg.uym = vload<T, VEC>(bc + lu - Nz);
+      rg.wc = vload<T, VEC>(bc + 2 * SU + lu); rg.wzr = ZR(rg.wc, bc + 2 * SU + lu);
+      {
+        const V t = vload<T, VEC>(bc + 2 * SU + lu - Nz);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rg.wym[j] = t[j];
+        rg.wym[VEC] = ZR(t, bc + 2 * SU + lu - Nz);
       }
-      // ---- (8) rotate
-      rg.um = rg.uc; rg.uc = rg.up; rg.up = un;
-      rg.vm = rg.vc; rg.vc = rg.vp; rg.vp = vn;
-      rg.wm = rg.wc; rg.wc = rg.wp; rg.wp = wn;
-      rg.wmzr = rg.wzr;
-      rg.vmyp = rg.vyp;
-      rg.cm = rg.cc;
-      Hu = hun; Hv = hvn; Hw = hwn;
+      { const T t = vm_from_right<T>(rg.eyzc[0]); rg.eyzzr = fixr ? rg.eyzzr : t; }      // EYZ[x, y, z0+VEC]
+      V qv;
+      vm_row<T, VEC, 1>(rg, k1, k2, msk, qv, first, last, active, acc);
+      if (active) vm_store<T, VEC, true>(oy + (int64_t)x * sv + o_uv, qv, first, last);
+      MFS_VM_PIN();
+      const V fyn = vload<T, VEC>(qn + 4 * cs), cymn = vload<T, VEC>(qn + 6 * cs - MFS_VM_NBR(c.pz)), exypn = vload<T, VEC>(qn + sc);
+      T eyzzrn = (T)0;
+      if (fixr) eyzzrn = qn[3 * cs + VEC];
+      const unsigned mskn = MFS_VM_MK(vm_mask<VEC>(mqn));
+      MFS_VM_PIN();
+      // ---- (5) w rows
+      rg.wc = vload<T, VEC>(bc + 2 * SU + lu); rg.wp = vload<T, VEC>(bn + 2 * SU + lu); rg.wm = vload<T, VEC>(bm + 2 * SU + lu);
+      rg.wyp = vload<T, VEC>(bc + 2 * SU + lu + Nz);
+      {
+        const V t = vload<T, VEC>(bc + 2 * SU + lu - Nz);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rg.wym[j] = t[j];
+      }
+      rg.wzl = ZL(rg.wc, bc + 2 * SU + lu); rg.wzr = ZR(rg.wc, bc + 2 * SU + lu);
+      rg.up = vload<T, VEC>(bn + lu); rg.upzl = ZL(rg.up, bn + lu);
+      rg.uc = vload<T, VEC>(bc + lu); rg.uzl = ZL(rg.uc, bc + lu);
+      rg.vc = vload<T, VEC>(bc + SU + lu); rg.vzl = ZL(rg.vc, bc + SU + lu);
+      rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vypzl = ZL(rg.vyp, bc + SU + lu + Nz);
+      { const T t = vm_from_left<T>(rg.cc[VEC - 1]); rg.czl = fixl ? rg.czl : t; }        // C[x, y, z0-1]
+      V qw;
+      vm_row<T, VEC, 2>(rg, k1, k2, msk, qw, first, last, active, acc);
+      if (active) vm_store<T, VEC, false>(oz + (int64_t)x * sw + o_w, qw, first, last);
+      MFS_VM_PIN();
+      const V fzn = vload<T, VEC>(qn + 5 * cs), exzpn = vload<T, VEC>(qn + cs + sc), eyzcn = vload<T, VEC>(qn + 3 * cs),
+              eyzypn = vload<T, VEC>(qn + 3 * cs + MFS_VM_NBR(c.pz));
+      T czln = (T)0;
+      if (fixl) czln = qn[6 * cs - 1];
+      MFS_VM_PIN();
+      // ---- (6) plane x+2 into its slot (its loads have had the whole step); next step's class samples take over
+      publish(bw, pn);
+      rg.cm = rg.cc; rg.cc = ccn;
+      rg.exyc = rg.exyp; rg.exyp = exypn; rg.exzc = rg.exzp; rg.exzp = exzpn;
+      rg.fx = fxn; rg.exyyp = exyypn; rg.exzzr = exzzrn;
+      rg.fy = fyn; rg.cym = cymn; rg.eyzzr = eyzzrn;
+      rg.fz = fzn; rg.eyzc = eyzcn; rg.eyzyp = eyzypn; rg.czl = czln;
+      msk = mskn;
     }
-    MFS_VISC_LDS_BARRIER();      // the next march stages into buffer 0
+    MFS_VISC_LDS_BARRIER();      // the next march stages into the ring while a slow wave may still read this one's planes
   }
   const double tot = block_sum<kVmBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;

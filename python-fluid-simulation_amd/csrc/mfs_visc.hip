@@ -236,7 +236,8 @@ k_grid_boundary_condition(G3 g, V3 gv, int vdt, V3 gm, int mdt, const void* sphi
 // every row, SURVEY.md 7 "hard parts"), and the z-1 / z+VEC neighbours of any vector are addressable.  Pads are 0.
 struct Compact {
   const void* vol[8];           // state dtype; [0] (e,e,e) unused
-  const unsigned char* msk[8];  // only the three face classes 3 (e,o,o), 5 (o,e,o), 6 (o,o,e)
+  const unsigned char* msk;     // one byte per compact index: bit c = the face of component c there is not solid
+                                // (`sphi >= 0` at the three face classes 3 (e,o,o), 5 (o,e,o), 6 (o,o,e))
   int N[3];
   int py, pz;                   // row / element pitch (see above)
   __host__ __device__ int dim(int p, int ax) const { return N[ax] + (((p >> (2 - ax)) & 1) ? 0 : 1); }
@@ -250,7 +251,7 @@ __host__ __device__ constexpr int fdiv2(int a) { return a >= 0 ? a / 2 : -((-a +
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_vcg_setup(int Nx, int Ny, int Nz, int py, int pz, const void* sphi, int sdt, const void* vol, int voldt, T* o1, T* o2,
-            T* o3, T* o4, T* o5, T* o6, T* o7, unsigned char* m3, unsigned char* m5, unsigned char* m6) {
+            T* o3, T* o4, T* o5, T* o6, T* o7, unsigned char* mp) {
   const int d1 = 2 * Ny + 1, d2 = 2 * Nz + 1;
   const int64_t n = (int64_t)(2 * Nx + 1) * d1 * d2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,9 +262,10 @@ k_vcg_setup(int Nx, int Ny, int Nz, int py, int pz, const void* sphi, int sdt, c
   const int64_t ci = ((int64_t)(ii >> 1) * py + (j >> 1)) * pz + (k >> 1);
   T* dst = p == 1 ? o1 : p == 2 ? o2 : p == 3 ? o3 : p == 4 ? o4 : p == 5 ? o5 : p == 6 ? o6 : o7;
   dst[ci] = (T)ldx(vol, voldt, i);
-  if (p == 3 || p == 5 || p == 6) {
-    unsigned char* m = p == 3 ? m3 : (p == 5 ? m5 : m6);
-    m[ci] = ldx(sphi, sdt, i) >= 0 ? 1 : 0;
+  if ((p == 3 || p == 5 || p == 6) && ldx(sphi, sdt, i) >= 0) {
+    // three nodes share the byte of a compact index: OR the component's bit into its (zeroed) 32-bit word
+    const unsigned bit = 1u << (p == 3 ? 0 : (p == 5 ? 1 : 2));
+    atomicOr(reinterpret_cast<unsigned*>(mp + (ci & ~(int64_t)3)), bit << (8 * (int)(ci & 3)));
   }
 }
 
@@ -281,33 +283,73 @@ struct Box3 { int lo[3], hi[3]; };   // face-index box [lo, hi) of one row
 // array-boundary faces, so they cannot matter; the initial q = A x (x = extrapolated velocity, non-zero
 // on solid faces) and the stand-alone apply use MASK=true.  The row's OWN mask (solid face -> out = 0)
 // always applies.
-template <int AXIS, bool MASK, typename S>
-__device__ __forceinline__ double vcg_row_s(const S& smp, double k1, double k2, bool own_ok, double& own_out) {
-  double vs[7];
+// NC cells at once: `smp` hands out the operands of cell j = 0 .. NC-1 (vol(j, p, ox, oy, oz), vel(j, comp, dx, dy, dz),
+// tap_ok(j, ...)).  The statements are ordered tap-major, cell-minor, so the NC accumulation chains -- each a strictly
+// dependent sequence of 15 fp64 operations -- sit interleaved in the instruction stream and hide each other's latency;
+// per cell the operations and their order are exactly those of the one-cell form below (same rounding, bit for bit).
+template <int AXIS, bool MASK, int NC, typename S>
+__device__ __forceinline__ void vcg_row_n(const S& smp, double k1, double k2, const bool (&own_ok)[NC], double (&out)[NC],
+                                          double (&own_out)[NC]) {
+  // The arithmetic is spelled out -- contraction off, fused multiply-adds written where they are wanted -- so that
+  // every kernel built on this function (one cell per lane, LDS tiles, x-marching vectors, boundary slabs) rounds
+  // identically whatever else the compiler finds around the call: where `(diag * own) - (k vol) * nb` may fuse
+  // either product into the subtraction, two kernels used to differ in the last bit.
+#pragma clang fp contract(off)
+  double vs[NC][7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     const int ax = kD0[AXIS][0] + kVolOff[k][0], ay = kD0[AXIS][1] + kVolOff[k][1], az = kD0[AXIS][2] + kVolOff[k][2];
     const int p = ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1);
-    vs[k] = smp.vol(p, fdiv2(ax), fdiv2(ay), fdiv2(az));
-  }
-  const double own = smp.vel(AXIS, 0, 0, 0);
-  double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const double t = kDiagFac[AXIS][k] == 2 ? 2 * vs[k + 1] : vs[k + 1];
-    s = k == 0 ? t : s + t;
+    for (int j = 0; j < NC; ++j) vs[j][k] = smp.vol(j, p, fdiv2(ax), fdiv2(ay), fdiv2(az));
   }
-  double val = (vs[0] + k1 * s) * own;
+  double val[NC], s[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) own_out[j] = smp.vel(j, AXIS, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {      // 2 * vol is exact: the fused form of `s + 2 vol` rounds like the reference's
+    const bool two = kDiagFac[AXIS][k] == 2;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (k == 0) s[j] = two ? 2 * vs[j][1] : vs[j][1];
+      else s[j] = two ? __builtin_fma(2.0, vs[j][k + 1], s[j]) : s[j] + vs[j][k + 1];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j) val[j] = __builtin_fma(k1, s[j], vs[j][0]) * own_out[j];          // diag * v   (:268-269)
 #pragma unroll
   for (int t = 0; t < 14; ++t) {
     const VTap tp = kTaps[AXIS][t];
-    double nbv = smp.vel(tp.comp, tp.dx, tp.dy, tp.dz);
-    // the tap's mask sample is the validity of the tapped face itself (see header)
-    if (MASK) nbv = smp.tap_ok(tp.comp, tp.dx, tp.dy, tp.dz) ? nbv : 0.0;
-    val += tp.sgn * ((tp.fac == 2 ? k2 : k1) * vs[tp.vol] * nbv);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      double nbv = smp.vel(j, tp.comp, tp.dx, tp.dy, tp.dz);
+      // the tap's mask sample is the validity of the tapped face itself (see header)
+      if (MASK) nbv = smp.tap_ok(j, tp.comp, tp.dx, tp.dy, tp.dz) ? nbv : 0.0;
+      const double kv = (tp.fac == 2 ? k2 : k1) * vs[j][tp.vol];   // `scale * mu * vol` first, as the reference evaluates it
+      val[j] = __builtin_fma(tp.sgn > 0 ? kv : -kv, nbv, val[j]);
+    }
   }
-  own_out = own;
-  return own_ok ? val : 0.0;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) out[j] = own_ok[j] ? val[j] : 0.0;
+}
+
+// one cell: S::vol(p, ox, oy, oz), S::vel(comp, dx, dy, dz), S::tap_ok(comp, dx, dy, dz)
+template <typename S>
+struct OneCellSampler {
+  const S& s;
+  __device__ __forceinline__ double vol(int, int p, int ox, int oy, int oz) const { return s.vol(p, ox, oy, oz); }
+  __device__ __forceinline__ double vel(int, int comp, int dx, int dy, int dz) const { return s.vel(comp, dx, dy, dz); }
+  __device__ __forceinline__ bool tap_ok(int, int comp, int dx, int dy, int dz) const { return s.tap_ok(comp, dx, dy, dz); }
+};
+
+template <int AXIS, bool MASK, typename S>
+__device__ __forceinline__ double vcg_row_s(const S& smp, double k1, double k2, bool own_ok, double& own_out) {
+  const OneCellSampler<S> one{smp};
+  const bool ok[1] = {own_ok};
+  double out[1], own[1];
+  vcg_row_n<AXIS, MASK, 1>(one, k1, k2, ok, out, own);
+  own_out = own[0];
+  return out[0];
 }
 
 template <typename T>
@@ -326,7 +368,7 @@ struct GlobalSampler {
     return (double)v.p[comp][fidx(comp, dx, dy, dz)];
   }
   __device__ __forceinline__ bool tap_ok(int comp, int dx, int dy, int dz) const {
-    return c.msk[face_class(comp)][c.idx(x + dx, y + dy, z + dz)] != 0;
+    return ((c.msk[c.idx(x + dx, y + dy, z + dz)] >> comp) & 1) != 0;
   }
 };
 
@@ -334,7 +376,7 @@ template <typename T, int AXIS, bool MASK>
 __device__ __forceinline__ double vcg_row(const Compact& c, double k1, double k2, const Vec3T<T>& v, int x, int y,
                                           int z, double& own_out) {
   const GlobalSampler<T> smp{c, v, x, y, z};
-  const bool own_ok = c.msk[face_class(AXIS)][c.idx(x, y, z)] != 0;
+  const bool own_ok = ((c.msk[c.idx(x, y, z)] >> AXIS) & 1) != 0;
   return vcg_row_s<AXIS, MASK>(smp, k1, k2, own_ok, own_out);
 }
 
@@ -544,7 +586,6 @@ k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   int d1[V::NARR], d2[V::NARR];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { ap[a] = v.p[a]; d1[a] = Ny + (a == 1); d2[a] = Nz + (a == 2); }
-#pragma unroll
   int q1[V::NARR], q2[V::NARR];                               // storage pitches (rows per plane, elements per row)
 #pragma unroll
   for (int a = 0; a < 3; ++a) { q1[a] = d1[a]; q2[a] = d2[a]; }
@@ -597,9 +638,8 @@ k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     if (more) stage_load(x + 2);                               // in flight while this plane is computed
     const int64_t f0 = ((int64_t)x * Ny + y) * Nz + z, f1 = ((int64_t)x * (Ny + 1) + y) * Nz + z,
                   f2 = ((int64_t)x * Ny + y) * (Nz + 1) + z;
-    const int64_t fm = c.idx(x, y, z);
-    const bool ok0 = c.msk[face_class(0)][fm] != 0, ok1 = c.msk[face_class(1)][fm] != 0,
-               ok2 = c.msk[face_class(2)][fm] != 0;
+    const unsigned fm = c.msk[c.idx(x, y, z)];
+    const bool ok0 = (fm & 1) != 0, ok1 = (fm & 2) != 0, ok2 = (fm & 4) != 0;
     double o0, o1, o2;
     const double r0 = vcg_row_s<0, false>(smp, k1, k2, ok0, o0);
     const double r1 = vcg_row_s<1, false>(smp, k1, k2, ok1, o1);
@@ -649,6 +689,7 @@ struct mfs_vcg3d {
   int merge_slabs; // 1 / 0: the fused box and the boundary slabs in one launch (default) / two
   int march;       // 1 (default): CG applies run the x-marching vector kernel (mfs_vcg_march.h) where the grid allows it
   int march_bpc;   // its workgroups per CU (2: what its register budget makes resident)
+  int march_vec;   // experiment: 2 = 8-byte vectors for fp32 state
   mfs_p2p* p2p;    // window transport of the slab loop (mfs_vcg3d_attach_p2p); null: the caller moves halos / scalars
 };
 
@@ -702,17 +743,43 @@ static int vslab_grid(const Box3& b) {
 }
 
 // can the x-marching vector kernel serve this engine / these operands?  (rows of whole 16-byte vectors, 16-byte aligned
-// vectors, one halo vector per thread, both plane buffers within the default 64 KB of dynamic LDS)
-template <typename T>
+// vectors, one halo vector per thread, the ring of plane buffers within the CU's LDS: two workgroups per CU up to 80 KB
+// each, one beyond that -- measured at 256^3 fp32: one workgroup per CU runs within 7 % of two, the kernel is paced
+// by its instruction stream, not by occupancy)
+constexpr size_t kVmMaxLds = 152 * 1024;
+template <typename T, int VEC = VecOf<T>::N>
 static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
-  constexpr int VEC = VecOf<T>::N;
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   if (!h->march || Nx < 3 || Ny < 3 || Nz % VEC != 0 || Nz < 2 * VEC) return false;
-  if (2 * (Nz / VEC + 1) > kVmBlock) return false;
-  if ((size_t)2 * vm_buf_elems<VEC>(Nz) * sizeof(T) > 64 * 1024) return false;
+  if (2 * (Nz / VEC) > kVmBlock) return false;
+  if (vm_lds_bytes<T, VEC>(Nz) > kVmMaxLds) return false;
   if (((uintptr_t)v % 16) != 0 || ((uintptr_t)out % 16) != 0) return false;
   if ((int64_t)(Ny + 1) * (Nz + 4) > (int64_t)0x7fffffff / 2) return false;     // 32-bit in-plane offsets
   return true;
+}
+
+template <typename T, int VEC, int WAVES>
+static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
+                            int* nparts) {
+  const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
+  const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + kVmBlock - 1) / kVmBlock;
+  const int64_t total = (int64_t)tiles * (Nx - 2);
+  const size_t lds = vm_lds_bytes<T, VEC>(Nz);
+  const int bpc = lds > 80 * 1024 ? 1 : h->march_bpc;
+  const int gmain = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * bpc));
+  const Box3 b0 = vslab_box(h, 0), b1 = vslab_box(h, 1), b2 = vslab_box(h, 2);
+  const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
+  static bool attr_set = false;        // per instantiation: more than the default 64 KB of dynamic LDS
+  if (!attr_set) {
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kVmMaxLds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
+                     h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial, done);
+  MFS_LAUNCH_CHECK();
+  *nparts = gmain + g0 + g1 + g2;
+  return MFS_OK;
 }
 
 template <typename T, bool MASK>
@@ -723,21 +790,10 @@ static int vcg_apply_TM(mfs_vcg3d* h, const void* v, void* out, double* partial,
   Vec3T<T> vv{{vb + h->off[0], vb + h->off[1], vb + h->off[2]}};
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   int used = 0;
-  if (!MASK && !h->tiled && vcg_march_ok<T>(h, v, out)) {
-    constexpr int VEC = VecOf<T>::N;
-    const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + kVmBlock - 1) / kVmBlock;
-    const int64_t total = (int64_t)tiles * (Nx - 2);
-    const int gmain = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * h->march_bpc));
-    const Box3 b0 = vslab_box(h, 0), b1 = vslab_box(h, 1), b2 = vslab_box(h, 2);
-    const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
-    const size_t lds = (size_t)2 * vm_buf_elems<VEC>(Nz) * sizeof(T);
-    hipLaunchKernelGGL((k_vcg_apply_march<T, VEC>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
-                       h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial,
-                       done);
-    MFS_LAUNCH_CHECK();
-    *nparts = gmain + g0 + g1 + g2;
-    return MFS_OK;
-  }
+  if constexpr (sizeof(T) == 4) if (!MASK && !h->tiled && h->march_vec == 2 && vcg_march_ok<T, 2>(h, v, out))
+    return vcg_march_launch<T, 2, 3>(h, vv, ob, partial, done, st, nparts);      // experiment: 8-byte vectors, 3 waves / SIMD
+  if (!MASK && !h->tiled && vcg_march_ok<T>(h, v, out))
+    return vcg_march_launch<T, VecOf<T>::N, MFS_VMARCH_MIN_WAVES>(h, vv, ob, partial, done, st, nparts);
   // (1) the box where all three rows are interior faces: one fused launch
   if (Nx >= 3 && Ny >= 3 && Nz >= 3) {
     const int nbz = (Nz - 2 + 63) / 64, nby = (Ny - 2 + 3) / 4;
@@ -1085,7 +1141,7 @@ size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   size_t tot = core_ws_bytes() + 4096;
   for (int p = 1; p < 8; ++p) tot += align_up((size_t)class_count(gres, p) * dtype_size(dt), 4096) + 4096;
-  for (int p : {3, 5, 6}) tot += align_up((size_t)class_count(gres, p), 4096);
+  tot += align_up((size_t)class_count(gres, 0), 4096);       // the packed mask bytes
   return tot;
 }
 
@@ -1115,9 +1171,8 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->cp.py = h->g.N[1] + 1;
   h->cp.pz = h->g.N[2] + 4;
   h->cp.vol[0] = nullptr;
-  for (int q = 0; q < 8; ++q) h->cp.msk[q] = nullptr;
   for (int q = 1; q < 8; ++q) { h->cp.vol[q] = p; p += align_up((size_t)class_count(gres, q) * h->c.elt, 4096) + 4096; }
-  for (int q : {3, 5, 6}) { h->cp.msk[q] = (unsigned char*)p; p += align_up((size_t)class_count(gres, q), 4096); }
+  h->cp.msk = (unsigned char*)p; p += align_up((size_t)class_count(gres, 0), 4096);
   h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
   h->is_setup = false;
   h->mask_cg = env_int("MFS_VISC_MASK_CG", 0);
@@ -1129,6 +1184,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->merge_slabs = env_int("MFS_VISC_MERGE", 1);
   h->march = env_int("MFS_VISC_MARCH", 1);
   h->march_bpc = std::max(1, env_int("MFS_VISC_MARCH_BPC", 2));
+  h->march_vec = env_int("MFS_VISC_MARCH_VEC", 0);
   h->xchunk_tiled = std::max(1, env_int("MFS_VISC_XCHUNK", 32));
   h->k1 = h->k2 = 0.0;
   if (hipMemsetAsync(workspace, 0, mfs_vcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
@@ -1154,16 +1210,17 @@ int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int
   MFS_REQUIRE(dtype_ok(sphi_dt) && dtype_ok(vol_dt), "dtype");
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   const int64_t n = (int64_t)(2 * Nx + 1) * (2 * Ny + 1) * (2 * Nz + 1);
-  unsigned char *m3 = (unsigned char*)h->cp.msk[3], *m5 = (unsigned char*)h->cp.msk[5], *m6 = (unsigned char*)h->cp.msk[6];
+  unsigned char* mp = (unsigned char*)h->cp.msk;
+  MFS_HIP_TRY(hipMemsetAsync(mp, 0, align_up((size_t)h->cp.stored(), 4), (hipStream_t)stream));   // the setup kernel ORs bits in
   void* const* v = (void* const*)h->cp.vol;
   if (h->dt == MFS_F32)
     hipLaunchKernelGGL((k_vcg_setup<float>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, h->cp.py,
                        h->cp.pz, sphi, sphi_dt, vol, vol_dt, (float*)v[1], (float*)v[2], (float*)v[3], (float*)v[4], (float*)v[5],
-                       (float*)v[6], (float*)v[7], m3, m5, m6);
+                       (float*)v[6], (float*)v[7], mp);
   else
     hipLaunchKernelGGL((k_vcg_setup<double>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Nx, Ny, Nz, h->cp.py,
                        h->cp.pz, sphi, sphi_dt, vol, vol_dt, (double*)v[1], (double*)v[2], (double*)v[3], (double*)v[4],
-                       (double*)v[5], (double*)v[6], (double*)v[7], m3, m5, m6);
+                       (double*)v[5], (double*)v[6], (double*)v[7], mp);
   MFS_LAUNCH_CHECK();
   h->k1 = scale * mu;          // `scale * mu * ...`      (left to right, as the reference evaluates it)
   h->k2 = 2 * scale * mu;      // `2 * scale * mu * ...`
@@ -1178,6 +1235,16 @@ int mfs_vcg3d_apply(mfs_vcg3d* h, const void* v, void* out, mfs_stream stream) {
   if (int e = vcg_apply(h, v, out, h->c.part_dq, false, true, (hipStream_t)stream, &np)) return e;
   h->c.n_part_dq = np;
   return MFS_OK;
+}
+
+int mfs_vcg3d_apply_kernel(mfs_vcg3d* h) {
+  if (!h) return 0;
+  if (h->tiled) return 1;
+  static const char aligned[16] __attribute__((aligned(16))) = {0};
+  const void* d = h->c.d ? h->c.d : (const void*)aligned;
+  const void* q = h->c.q ? h->c.q : (const void*)aligned;
+  const bool ok = h->dt == MFS_F32 ? vcg_march_ok<float>(h, d, q) : vcg_march_ok<double>(h, d, q);
+  return ok ? 2 : 0;
 }
 
 int mfs_vcg3d_bind(mfs_vcg3d* h, void* b, void* x, void* d, void* r, void* q) {

@@ -74,6 +74,10 @@ class VcgEngine:
         _lib.check(self.lib.mfs_vcg3d_bind(self.h, *[T.ptr(t) for t in ts]), "mfs_vcg3d_bind")
         self._bound = ts
 
+    def apply_kernel(self):
+        """which kernel the CG applies take for the engine as bound: "march" | "tiled" | "scalar" (bit-identical)"""
+        return {2: "march", 1: "tiled", 0: "scalar"}[int(self.lib.mfs_vcg3d_apply_kernel(self.h))]
+
     def begin(self, tol):
         _lib.check(self.lib.mfs_vcg3d_begin(self.h, float(tol), T.stream()), "mfs_vcg3d_begin")
 

@@ -1,0 +1,37 @@
+"""GPU: the viscosity CG apply kernel of the engine as configured by the environment (MFS_LIB, MFS_VISC_*): back-to-back
+launch time and CG iteration time on the buckling-like scene.  usage: python tools/vapply_time.py N [f32|f64] [tag]"""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "python-fluid-simulation_amd"), REPO]
+import torch
+from mfs import scenes
+import solver.ViscosityCGSolver3D as V
+N = int(sys.argv[1]); dts = sys.argv[2] if len(sys.argv) > 2 else "f32"; tag = sys.argv[3] if len(sys.argv) > 3 else ""
+dev = torch.device("cuda:0"); gres = (N, N, N)
+sc = scenes.viscosity_scene_3d(gres, seed=3, device=dev)
+s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision=dts, device=dev)
+scale = sc["dt"] / s.cell_vol / sc["rho"]
+torch.div(sc["lvol"], s.cell_vol * 0.125, out=s.vol)
+s.x_x.copy_(sc["vx"]); s.x_y.copy_(sc["vy"]); s.x_z.copy_(sc["vz"])
+V.extrapolate(gres, 3, s.x_x, s.x_y, s.x_z, sc["sphi"])
+V.initialize_solver(gres, scale, 50.0, s.x_x, s.x_y, s.x_z, sc["sphi"], sc["sv"], s.vol, s.b_x, s.b_y, s.b_z)
+e = s._engine
+e.setup(scale, 50.0, sc["sphi"], s.vol)
+f = s._flat
+e.bind(f["b"], f["x"], f["d"], f["r"], f["q"])
+e.begin(0.0); e.iterate(10); torch.cuda.synchronize()
+res = {"tag": tag, "N": N, "dtype": dts, "kernel": e.apply_kernel()}
+for name, fn, reps in (("apply_b2b_us", e.phase_apply, 40),):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(); a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    res[name] = round(a.elapsed_time(b) / reps * 1e3, 1)
+its = []
+for _ in range(3):
+    t0 = time.perf_counter(); e.iterate(40); torch.cuda.synchronize(); its.append(round((time.perf_counter() - t0) / 40 * 1e6, 1))
+res["iter_us"] = its
+cells = N ** 3
+esz = 4 if dts == "f32" else 8
+res["apply_alg_GBs(13 scalars + 3 mask bytes per cell)"] = round((13 * esz + 3) * cells / (res["apply_b2b_us"] * 1e-6) / 1e9, 1)
+print(json.dumps(res))
