@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--local-grid", default="", help="1 GPU experiments: Nx,Ny,Nz of the grid (e.g. 66,512,512 = one rank's slab of the 8-GPU run)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64-line", action="store_true", help="skip the fp64-state sub-measurement (default precision of the drop-in)")
     ap.add_argument("--force-phases", action="store_true",
                     help="1 GPU: run the phase-by-phase multi-GPU driver loop (1-rank RCCL group) to price its host overhead")
     ap.add_argument("--transport", default="auto", choices=["auto", "p2p", "rccl"],
@@ -92,6 +93,89 @@ def cpu_baseline(args, gres, scene_seed):
             "sample": sample, "iters_per_s": iters / dt, "host_cpus": os.cpu_count()}
 
 
+def build_problem(torch, dev, tdt, lgres, ggrid, seed, x_range):
+    """the bench workload on this rank's slab: weights, RHS, level set, CG vectors (all resident in HBM)"""
+    from mfs import scenes
+    import solver.PressureCGSolver3D as P
+    import solver.SolidFraction3D as S
+    sc = scenes.pressure_scene_3d(ggrid, seed=seed, x_range=x_range, device=dev)
+    wx = torch.zeros((lgres[0] + 1, lgres[1], lgres[2]), dtype=tdt, device=dev)
+    wy = torch.zeros((lgres[0], lgres[1] + 1, lgres[2]), dtype=tdt, device=dev)
+    wz = torch.zeros((lgres[0], lgres[1], lgres[2] + 1), dtype=tdt, device=dev)
+    S.compute_solid_frac(lgres, sc["sphi"], wx, wy, wz)
+    b, x, d, r, q = (torch.zeros(lgres, dtype=tdt, device=dev) for _ in range(5))
+    P.initialize_solver(sc["cell_size"], lgres, sc["vx"], sc["vy"], sc["vz"], sc["sphi"], sc["sv"], sc["lphi"],
+                        b, wx, wy, wz)
+    lphi = sc["lphi"]
+    del sc
+    torch.cuda.empty_cache()
+    return wx, wy, wz, lphi, (b, x, d, r, q)
+
+
+def parity_check(args, torch, dev, tdt, lgres, seed, iters=10):
+    """default engine (as timed) vs oracle/mfs_oracle_c.c on the bench workload: residual history over the first
+    `iters` iterations (fp32 state: north_star's 1e-5 rel; fp64 state: 1e-9) and x after finish()"""
+    import numpy as np
+    from mfs.pcg import PcgEngine
+    from oracle import cbaseline
+    tol = 1e-5 if tdt == torch.float32 else 1e-9
+    wx, wy, wz, lphi, (b, x, d, r, q) = build_problem(torch, dev, tdt, lgres, lgres, seed, None)
+    eng = PcgEngine(lgres, tdt, dev)
+    eng.setup(lphi, wx, wy, wz)
+    eng.bind(b, x, d, r, q)
+    eng.begin(0.0)
+    eng.iterate(iters)
+    eng.finish()
+    torch.cuda.synchronize()
+    h = eng.history()[: 2 * iters + 1]
+    form = eng.loop_info()
+    host = lambda t: t.double().cpu().numpy()  # noqa: E731
+    # the oracle starts from the SAME stored RHS and weights (state-precision values), and computes in fp64
+    ref = cbaseline.cg(lgres, host(b), host(lphi), host(wx), host(wy), host(wz), 0.0, iters, 2 * iters + 1)
+    hr = ref["history"]
+    dev_h = float(np.max(np.abs(h - hr) / np.abs(hr)))
+    xr = ref["x"]
+    dev_x = float(np.max(np.abs(host(x) - xr)) / np.max(np.abs(xr)))
+    ok = bool(len(h) == len(hr) == 2 * iters + 1 and dev_h < tol and dev_x < tol)
+    out = {"checked": "default engine as timed: " + ", ".join(k for k, v in form.items() if v), "iterations": iters,
+           "window": f"first {iters} CG iterations (the history is rounding-chaotic beyond a leading window: DESIGN.md section 3)",
+           "history_max_rel_dev": dev_h, "x_max_dev_rel_to_max": dev_x, "tolerance": tol, "ok": ok,
+           "oracle": "oracle/mfs_oracle_c.c (C/OpenMP restatement, fp64), outside the timed region"}
+    del eng, wx, wy, wz, lphi, b, x, d, r, q
+    torch.cuda.empty_cache()
+    if not ok:
+        raise AssertionError(f"bench parity self-check failed: {out}")
+    return out
+
+
+def f64_leg(args, torch, dev, lgres, seed):
+    """the same workload with fp64 solver state -- the drop-in's default precision"""
+    from mfs.pcg import PcgEngine
+    steps, warm = max(20, args.steps // 3), max(5, args.warmup // 3)
+    wx, wy, wz, lphi, (b, x, d, r, q) = build_problem(torch, dev, torch.float64, lgres, lgres, seed, None)
+    eng = PcgEngine(lgres, torch.float64, dev)
+    eng.setup(lphi, wx, wy, wz)
+    eng.bind(b, x, d, r, q)
+    eng.begin(0.0)
+    eng.iterate(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.iterate(steps)
+    eng.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.poll()
+    assert st["iterations"] == warm + steps and st["delta"] == st["delta"], st
+    cells = lgres[0] * lgres[1] * lgres[2]
+    pc = parity_check(args, torch, dev, torch.float64, lgres, seed)
+    out = {"dtype": "f64", "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 5),
+           "value": round(cells * steps / dt / 1e6, 1), "unit": "Mcells/s", "iters_per_s": round(steps / dt, 2),
+           "cg_iteration_hbm_gbs": round(15 * cells * 8 / (dt / steps) / 1e9, 1), "parity_check": pc}
+    del eng, wx, wy, wz, lphi, b, x, d, r, q
+    torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks as child processes
     (one per GPU, `python -m torch.distributed.run`), relay their output -- rank 0 prints the JSON line -- and return
@@ -136,11 +220,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout())
 
-    from mfs import _lib, scenes
+    from mfs import _lib
     from mfs.pcg import PcgEngine
     from mfs import dist as mdist
-    import solver.PressureCGSolver3D as P
-    import solver.SolidFraction3D as S
 
     _lib.load()
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
@@ -161,17 +243,7 @@ def main():
     part = mdist.SlabPartition(ggrid[0], world, rank)
     lo, hi = part.local_range            # cell planes held locally
     lgres = (hi - lo, ggrid[1], ggrid[2])
-    sc = scenes.pressure_scene_3d(ggrid, seed=seed, x_range=(lo, hi), device=dev)
-    wx = torch.zeros((lgres[0] + 1, lgres[1], lgres[2]), dtype=tdt, device=dev)
-    wy = torch.zeros((lgres[0], lgres[1] + 1, lgres[2]), dtype=tdt, device=dev)
-    wz = torch.zeros((lgres[0], lgres[1], lgres[2] + 1), dtype=tdt, device=dev)
-    S.compute_solid_frac(lgres, sc["sphi"], wx, wy, wz)
-    b, x, d, r, q = (torch.zeros(lgres, dtype=tdt, device=dev) for _ in range(5))
-    P.initialize_solver(sc["cell_size"], lgres, sc["vx"], sc["vy"], sc["vz"], sc["sphi"], sc["sv"], sc["lphi"],
-                        b, wx, wy, wz)
-    lphi = sc["lphi"]
-    del sc
-    torch.cuda.empty_cache()
+    wx, wy, wz, lphi, (b, x, d, r, q) = build_problem(torch, dev, tdt, lgres, ggrid, seed, (lo, hi))
     eng = PcgEngine(lgres, tdt, dev)
     eng.setup(lphi, wx, wy, wz)
     eng.bind(b, x, d, r, q)
@@ -307,38 +379,57 @@ def main():
 
     # ---- roofline of the dominant kernel (stencil apply), measured with HIP events
     rf = None
+    parity = None
+    f64_line = None
     if rank == 0:
         Nx, Ny, Nz = lgres
-        # the dominant kernel of the timed loop is the stencil apply WITH the direction update folded in:
-        # SURVEY.md 8(d)'s stencil figure (6N^3+3N^2 scalars: v,4 coefficient arrays in, out) plus the update's
-        # r in and d_new out, with d_old taking the place of v = 8N^3+3N^2 scalars per launch
-        # ... and, where the loop defers it (grids beyond the Infinity Cache), the previous iteration's x update:
-        # x in, x out (d_old is re-read from cache and not counted) = 10N^3+3N^2
+        cells_l = Nx * Ny * Nz
+        reps = max(20, min(args.steps, 200))
+
+        def time_apply(engine, n):
+            """average duration of the stencil launch inside real CG iterations: HIP events (on the stream the kernel is
+            launched on) bracket each apply launch of n native iterations"""
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for s_ev, e_ev in ev:
+                s_ev.record()
+                engine.native_apply()       # the stencil launch of one native iteration
+                e_ev.record()
+                engine.native_finish()
+            torch.cuda.synchronize()
+            return sum(a.elapsed_time(b_) for a, b_ in ev) / n
+
+        def alg_bytes_of(form, fused):
+            # SURVEY.md 8(d)'s stencil figure (6N^3+3N^2 scalars: v, 4 coefficient arrays in, out); with the direction
+            # update folded in: + r in, d_new out, d_old in the place of v = 8N^3+3N^2; with the previous iteration's
+            # x update deferred into the launch as well: + x in, x out = 10N^3+3N^2 (DESIGN.md section 4)
+            per = 6 if not fused else (10 if form["deferred_x_update"] else 8)
+            return (per * cells_l + 3 * Ny * Nz) * esz
+
+        def leg(engine, fused, label):
+            engine.set_fuse(fused)
+            engine.begin(0.0)
+            engine.iterate(2)
+            form = engine.loop_info()
+            ms = time_apply(engine, reps)
+            ab = alg_bytes_of(form, fused)
+            return {"kernel": label, "algorithmic_bytes": ab, "kernel_ms": round(ms, 5),
+                    "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
         form = eng.loop_info()
-        alg_bytes = ((10 if form["deferred_x_update"] else 8) * Nx * Ny * Nz + 3 * Ny * Nz) * esz
+        alg_bytes = alg_bytes_of(form, True)
         if transport != "single":          # leave the slab loops' state behind: plain single-domain iterations
             eng.begin(0.0)
             eng.iterate(2)
-        reps = max(20, min(args.steps, 200))
-        # inside real CG iterations: HIP events (on the stream the kernel is launched on) bracket each
-        # apply launch; an empty event pair is timed the same way for reference
         cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
         for s_ev, e_ev in cal:
             s_ev.record()
             e_ev.record()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for s_ev, e_ev in evs:
-            s_ev.record()
-            eng.native_apply()          # the stencil launch of one native iteration (fused direction update)
-            e_ev.record()
-            eng.native_finish()
         torch.cuda.synchronize()
-        ev_over = sorted(s.elapsed_time(e) for s, e in cal)[len(cal) // 2]
-        ms_raw = sum(s.elapsed_time(e) for s, e in evs) / reps
+        ev_over = sorted(a.elapsed_time(b_) for a, b_ in cal)[len(cal) // 2]
         # NOT subtracted: an empty pair (~9 us) over-states what two records cost around a running kernel
         # (rocprofv3 gives 63.2 us for the kernel whose bracketed time is 66.5 us); the bracketed time is the
         # conservative figure and is what `achieved` uses.
-        ms_cg = ms_raw
+        ms_cg = time_apply(eng, reps)
         ms_b2b = None
         if args.b2b:   # back-to-back applies (Infinity-Cache-warm; NOT what the CG loop sees)
             s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -350,45 +441,75 @@ def main():
             torch.cuda.synchronize()
             ms_b2b = s_ev.elapsed_time(e_ev) / reps
         achieved = alg_bytes / (ms_cg * 1e-3) / 1e9
-        # the same measurement on the PLAIN stencil apply (6N^3 + 3N^2 scalars -- the figure
-        # BASELINE.md's 60 % target is stated on), inside the three-kernel form of the loop (direction update unfused)
-        eng.set_fuse(False)
-        eng.begin(0.0)
-        eng.iterate(2)
-        alg_plain = (6 * Nx * Ny * Nz + 3 * Ny * Nz) * esz
-        evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for s_ev, e_ev in evp:
-            s_ev.record()
-            eng.native_apply()
-            e_ev.record()
-            eng.native_finish()
-        torch.cuda.synchronize()
-        ms_plain = sum(s.elapsed_time(e) for s, e in evp) / reps
-        eng.set_fuse(True)
-        traffic = None
-        # HBM bytes per launch from PMC counters: collected by tools/pmc_bench.sh on this same command
-        # (separate rocprofv3 --pmc passes) and committed under profiles/; valid for the default workload only
-        pj = os.path.join(REPO, "profiles", "r01_pmc_apply.json")
-        if os.path.exists(pj) and transport == "single":
-            try:
-                pm = json.load(open(pj))
-                if pm.get("workload") == f"{Nx}x{Ny}x{Nz} {args.dtype}":
-                    traffic = pm.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         kname = ("k_pcg_apply_march<..., FUSE=true, XDEF=true> (stencil apply + d = r + beta d + x += alpha d_old)"
                  if form["deferred_x_update"] else "k_pcg_apply_march<..., FUSE=true> (stencil apply + d = r + beta d)")
+        # HBM bytes per launch from PMC counters: collected by tools/pmc_bench.sh on this same command in a SEPARATE
+        # run (rocprofv3 --pmc passes cannot ride in a timed run) and committed under profiles/ -- evidence, not a
+        # measurement of this run; valid for the default workload only.  traffic_frac = those bytes / this run's kernel
+        # time / peak: the fraction of the HBM roofline the kernel's real traffic amounts to.
+        traffic, traffic_src, dense_traffic = None, None, None
+        for name in ("r02_pmc_apply.json", "r01_pmc_apply.json"):
+            pj = os.path.join(REPO, "profiles", name)
+            if os.path.exists(pj) and transport == "single":
+                try:
+                    pm = json.load(open(pj))
+                    if pm.get("workload") == f"{Nx}x{Ny}x{Nz} {args.dtype}":
+                        traffic = pm.get("hbm_bytes_per_launch")
+                        dense_traffic = pm.get("dense_hbm_bytes_per_launch")
+                        traffic_src = {"file": "profiles/" + name, "collected": pm.get("collected"),
+                                       "commit": pm.get("commit"), "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                       "passes over this command (tools/pmc_bench.sh), FETCH_SIZE x2 (gfx950), not this run"}
+                        break
+                except Exception:
+                    pass
         rf = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+              "frac_is": "EFFECTIVE rate: algorithmic bytes / kernel time / peak.  With compressed coefficient access "
+                         "(default) the kernel moves fewer bytes than the algorithmic count on this scene, so this is "
+                         "not an HBM-utilisation figure -- traffic_frac and the `dense` legs are",
+              "traffic": traffic,
+              "traffic_frac": (round(traffic / (ms_cg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+              "traffic_source": traffic_src,
               "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5),
-              "kernel_ms_raw_events": round(ms_raw, 5), "event_pair_overhead_ms": round(ev_over, 5)}
-        rf["plain_stencil_apply"] = {"kernel": "k_pcg_apply_march<..., FUSE=false> (6N^3+3N^2 scalars, SURVEY.md 8(d))",
-                                     "algorithmic_bytes": alg_plain, "kernel_ms": round(ms_plain, 5),
-                                     "achieved": round(alg_plain / (ms_plain * 1e-3) / 1e9, 1),
-                                     "frac": round(alg_plain / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+              "event_pair_overhead_ms": round(ev_over, 5)}
+        # the PLAIN stencil apply (6N^3 + 3N^2 scalars -- the figure BASELINE.md's 60 % target is
+        # stated on), inside the three-kernel form of the loop (direction update unfused)
+        rf["plain_stencil_apply"] = leg(eng, False, "k_pcg_apply_march<..., FUSE=false> (6N^3+3N^2 scalars, SURVEY.md 8(d)), "
+                                                    "compressed coefficient access")
+        # DENSE coefficient access (every coefficient array read in full: what the kernel does on a scene without
+        # regular regions) -- the honest HBM figure: measured traffic ~ algorithmic bytes here
+        eng.set_compress(False)
+        rf["dense"] = {"plain_stencil_apply": leg(eng, False, "k_pcg_apply_march<..., FUSE=false, COMP=false>"),
+                       "fused": leg(eng, True, "k_pcg_apply_march<..., FUSE=true, COMP=false>"),
+                       "note": "set_compress(False): the 60 % target of BASELINE.json is judged on dense.plain_stencil_apply"}
+        if dense_traffic:
+            rf["dense"]["traffic_plain"] = dense_traffic
+        eng.set_compress(True)
+        eng.set_fuse(True)
+        # an ALL-MIXED scene: every face weight a random quarter, every cell fluid -- no vector is ZERO or REGULAR, the
+        # compressed access reads everything (plus the class bytes): the figure is then no property of the pool scene
+        gen = torch.Generator(device=dev).manual_seed(1)
+        rq = lambda shape: (torch.randint(1, 5, shape, generator=gen, device=dev).to(tdt) * 0.25)  # noqa: E731
+        wxm, wym, wzm = rq(tuple(wx.shape)), rq(tuple(wy.shape)), rq(tuple(wz.shape))
+        eng.setup(-torch.ones(lgres, dtype=tdt, device=dev), wxm, wym, wzm)
+        b.normal_(generator=gen)
+        rf["all_mixed_scene"] = {"plain_stencil_apply": leg(eng, False, "compressed access, every vector MIXED"),
+                                 "fused": leg(eng, True, "compressed access, every vector MIXED"),
+                                 "scene": "lphi = -1 everywhere, face weights uniform in {0.25, 0.5, 0.75, 1}"}
+        del wxm, wym, wzm
         if ms_b2b:
             rf["kernel_ms_back_to_back"] = round(ms_b2b, 5)
             rf["achieved_back_to_back"] = round(alg_bytes / (ms_b2b * 1e-3) / 1e9, 1)
+
+        # ---- parity self-check OUTSIDE the timed region: the engine exactly as timed (auto nontemporal / compressed /
+        # fused / deferred-x forms) on the bench workload, first 10 iterations' residual history and x after finish()
+        # against the oracle's C restatement (the checker; never the thing measured)
+        if world == 1 and transport == "single":
+            parity = parity_check(args, torch, dev, tdt, lgres, seed)
+
+        # ---- the drop-in's DEFAULT precision (fp64 state, like the reference): same workload, shorter timed loop
+        if world == 1 and transport == "single" and args.dtype == "f32" and not args.no_f64_line:
+            f64_line = f64_leg(args, torch, dev, lgres, seed)
     if world > 1:
         dist.barrier()
 
@@ -415,7 +536,15 @@ def main():
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5),
             "cg_iteration_hbm_gbs": round(iter_bytes / (dt / args.steps) / 1e9, 1),
             "roofline": rf,
+            "residual_parity": ("checked over a window: CG on this operator is chaotic in rounding (the oracle departs from "
+                                "its own history by > 1e-2 after ~30 iterations when only its summation order changes, "
+                                "tests/test_oracle_sensitivity.py), so north_star's 1e-5 rel residual match is asserted on "
+                                "the first 10 iterations at the bench size (parity_check) and 8-10 on the goldens"),
         }
+        if parity is not None:
+            out["parity_check"] = parity
+        if f64_line is not None:
+            out["f64_state"] = f64_line
         if shared:
             out["rehearsal"] = "all ranks share cuda:0 over gloo (MFS_BENCH_SHARED_GPU=1): code-path check, not a measurement"
         if tinfo:

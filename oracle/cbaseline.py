@@ -27,6 +27,13 @@ def _load():
         lib.mfs_oracle_pressure_cg3d.argtypes = [C.POINTER(C.c_int64), _pd, _pd, _pd, _pd, _pd, _pd, _pd, _pd, _pd,
                                                  C.c_double, C.c_int64, C.c_void_p, C.c_int64,
                                                  C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        lib.mfs_oracle_visc_apply3d.restype = None
+        lib.mfs_oracle_visc_apply3d.argtypes = [C.POINTER(C.c_int64), C.c_double, C.c_double, _pd, _pd, _pd, _pd, _pd, _pd,
+                                                _pd, _pd]
+        lib.mfs_oracle_visc_cg3d.restype = C.c_int64
+        lib.mfs_oracle_visc_cg3d.argtypes = [C.POINTER(C.c_int64), C.c_double, C.c_double, _pd, _pd, _pd, _pd, _pd, _pd, _pd,
+                                             C.c_double, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int)]
         _lib = lib
     return _lib
 
@@ -72,3 +79,27 @@ def time_cg(gres, b, lphi, wx, wy, wz, iters, nthreads=0):
     t0 = time.perf_counter()
     cg(gres, b, lphi, wx, wy, wz, 0.0, iters)
     return time.perf_counter() - t0, threads()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def visc_apply(gres, scale, mu, vx, vy, vz, ox, oy, oz, sphi, vol):
+    """mfs_oracle_visc_apply3d: the three operator rows on doubled-grid sphi / vol; outputs written in place"""
+    _load().mfs_oracle_visc_apply3d(_g(gres), float(scale), float(mu), _f64(vx), _f64(vy), _f64(vz), ox, oy, oz,
+                                    _f64(sphi), _f64(vol))
+
+
+def visc_cg(gres, scale, mu, b, x0, sphi, vol, tol, max_iter, hist_cap=0):
+    """mfs_oracle_visc_cg3d on flat [x-faces | y-faces | z-faces] vectors; `x0` is the initial guess (copied)"""
+    b = _f64(b).ravel()
+    x = _f64(x0).ravel().copy()
+    d, r, q = (np.zeros_like(x) for _ in range(3))
+    hist = np.zeros(max(hist_cap, 1))
+    delta, conv = C.c_double(), C.c_int()
+    it = _load().mfs_oracle_visc_cg3d(_g(gres), float(scale), float(mu), b, x, d, r, q, _f64(sphi), _f64(vol), tol,
+                                      max_iter, hist.ctypes.data if hist_cap else None, hist_cap, C.byref(delta),
+                                      C.byref(conv))
+    return dict(iterations=int(it), x=x, d=d, r=r, q=q, delta=delta.value, converged=bool(conv.value),
+                history=hist[: min(hist_cap, 2 * int(it) + 1)])

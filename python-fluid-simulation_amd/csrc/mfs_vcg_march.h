@@ -5,27 +5,32 @@
 //   tap order and arithmetic as every other form of the operator in this library, so results are bit-identical.
 //
 // Algorithmic HBM traffic per cell: d_x, d_y, d_z read, q_x, q_y, q_z written, 7 volume classes read = 13 scalars,
-// + 3 mask bytes.  What this kernel is about is moving exactly those bytes, once, in 16-byte pieces:
+// + 1 packed mask byte.  The kernel moves those bytes once, in 16-byte pieces:
 //
-//  * one work item = one 16-byte z-vector (4 fp32 / 2 fp64 cells) of an interior row y in [1, Ny-2]; all three
-//    operator rows (u, v, w faces) of its cells are computed by the same thread (they share most operands).
+//  * one work item = one 16-byte z-vector (4 fp32 / 2 fp64 cells) of an interior row y in [1, Ny-2]; the three
+//    operator rows (u, v, w faces) of its cells are computed by the same thread, component after component, the
+//    accumulation chains of the vector's cells interleaved (vcg_row_n) so that they hide each other's latency.
 //  * a workgroup owns a tile of 256 consecutive z-vectors of the flattened interior (y, z) plane and MARCHES ALONG X.
-//    The x-1 / x / x+1 planes of the three velocity components live in registers across steps, as do the volume
-//    samples that a step shares with the next one (cell centres of x-1, the xy- and xz-edge classes of x+1): x
-//    neighbours cost no memory traffic.
-//  * in-plane neighbours (y+-1 rows, z+-1 cells) of the three velocity components come from an LDS image of the plane
-//    tile plus one row of halo each side, per component, double buffered, ONE barrier per plane that waits on lgkmcnt
-//    only, so the global prefetch of the next plane stays in flight across it.  The image mirrors memory: for the u
-//    and v components (rows of Nz) every access is an aligned 16-byte one; the w component has rows of Nz+1 elements,
-//    which no vector alignment survives -- its global accesses are unaligned 16-byte ones (the hardware splits them)
-//    and its LDS accesses scalar.  The step's one look into plane x+1 off its own row (u[x+1,y-1,z], u[x+1,y,z-1]:
-//    the cross taps of the v and w rows) is served from the image published in the SAME step, read behind the barrier.
-//  * the seven volume classes and the three mask arrays are solver-owned and stored with one uniform, 16-byte aligned
-//    pitch (struct Compact): one per-thread offset serves them all, own vectors and the three neighbour rows
-//    (C[y-1], EXY[y+1], EYZ[y+1]) are aligned 16-byte loads that hit in L1/L2 behind the owner's.
+//  * the velocity operands live in LDS: a ring of four plane slots, each holding the three components' images of the
+//    plane tile plus one row of halo each side ([Nz | tile | Nz], mirroring the memory of the u / v components, so every
+//    LDS access is an aligned 16-byte one; the w component -- rows of Nz+1 in memory, which no vector alignment survives --
+//    is loaded / stored with unaligned 16-byte global accesses and kept in the same row-of-Nz image).  Planes x-1, x and
+//    x+1 are read (own rows, y+-1 rows), plane x+2 -- requested at the top of the step, a whole step in flight -- is
+//    written at its end; ONE barrier per plane, waiting on lgkmcnt only.  The ring is the register file of the march:
+//    nothing velocity is carried in VGPRs across steps, each phase reads what it needs and lets it go.
+//  * z-1 / z+VEC neighbours come from the neighbouring lane by DPP (wave_shr / wave_shl); only where a wave's 64 vectors
+//    do not start on a row boundary do lanes 0 / 63 read theirs (one lane, exec-masked).
+//  * the seven volume classes and the packed mask bytes are solver-owned and stored with one uniform, 16-byte aligned
+//    pitch and at one constant stride (struct Compact): one per-thread offset and one base pointer serve them all.  The
+//    samples only one phase reads are replaced, right after that phase, by the NEXT step's (a whole step in flight); the
+//    x-1 / x+1 samples a step shares with its neighbours are carried in registers.
 //  * balanced, XCD-aware work split exactly as in mfs_pcg_apply.h: the (tile, plane) sequence, tile-major, is cut into
 //    gridDim equal contiguous segments; blocks with equal blockIdx % 8 (one XCD, one L2) get adjacent segments.
 //  * the d.q partial sums ride along; no atomics, bitwise reproducible.
+// What bounds it (256^3 fp32, MI355X; tools/vm_stamps.py, tools/pmc_sq.sh, probes below): not HBM (1.2 GB moved in 208 us,
+// the same time with the arithmetic removed and with one workgroup per CU instead of two) but the length of a wave's own
+// instruction stream between two barriers -- ~1000 instructions per plane, of which ~20 vector-memory and ~75 LDS
+// instructions whose issue the wave pays itself.
 #pragma once
 
 #ifndef MFS_VMARCH_MIN_WAVES
@@ -184,7 +189,8 @@ struct VmSampler {
 template <typename T, int VEC, int AXIS>
 __device__ __forceinline__ void vm_row(const VmRegs<T, VEC>& rg, double k1, double k2, unsigned m, vec_t<T, VEC>& q, bool first,
                                        bool last, bool count, double& acc) {
-  constexpr int NC = (MFS_VM_CELL_GROUP > 0 && MFS_VM_CELL_GROUP < VEC && VEC % MFS_VM_CELL_GROUP == 0) ? MFS_VM_CELL_GROUP : VEC;
+  constexpr int G = MFS_VM_CELL_GROUP > 0 ? MFS_VM_CELL_GROUP : VEC;
+  constexpr int NC = (G < VEC && VEC % G == 0) ? G : VEC;
 #pragma unroll
   for (int j0 = 0; j0 < VEC; j0 += NC) {
     const VmSampler<T, VEC> smp{rg, j0};
@@ -192,7 +198,23 @@ __device__ __forceinline__ void vm_row(const VmRegs<T, VEC>& rg, double k1, doub
     double out[NC], own[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) ok[j] = ((m >> (8 * (j0 + j) + AXIS)) & 1u) != 0;     // byte J of m: cell J; bit AXIS: this row
+#ifdef MFS_VM_PROBE_NOMATH     // timing probe (WRONG results): every operand touched once, no operator arithmetic
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 14; ++t) { const VTap tp = kTaps[AXIS][t]; a += (float)smp.vel(j, tp.comp, tp.dx, tp.dy, tp.dz); }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int ax = kD0[AXIS][0] + kVolOff[k][0], ay = kD0[AXIS][1] + kVolOff[k][1], az = kD0[AXIS][2] + kVolOff[k][2];
+        a += (float)smp.vol(j, ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1), fdiv2(ax), fdiv2(ay), fdiv2(az));
+      }
+      own[j] = smp.vel(j, AXIS, 0, 0, 0);
+      out[j] = ok[j] ? (double)a : 0.0;
+    }
+#else
     vcg_row_n<AXIS, false, NC>(smp, k1, k2, ok, out, own);
+#endif
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int J = j0 + j;
@@ -235,6 +257,22 @@ template <typename T, int VEC>
 __host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing * 3 * vm_su<VEC>(Nz) * sizeof(T); }
 
 #define MFS_VM_PIN() __builtin_amdgcn_sched_barrier(0)
+// In-kernel stamps (diagnostic build only, -DMFS_VM_STAMPS; tools/vm_stamps.py): where a step's cycles go.  One stamp =
+// s_memtime + lgkmcnt(0) in one statement, fenced by scheduling barriers; the segment sums of the first 64 workgroups'
+// waves go to the upper half of the partial-sum array, which nothing else reads.
+#ifdef MFS_VM_STAMPS
+#define MFS_VM_STAMP(k)                                                                  \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long t_;                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    stamp_sum[k] += t_ - stamp_last;                                                      \
+    stamp_last = t_;                                                                      \
+  } while (0)
+#else
+#define MFS_VM_STAMP(k) do {} while (0)
+#endif
 #ifdef MFS_VM_PROBE_NOSCAL     // traffic probe (WRONG results): no z-neighbour scalar loads, no mask loads
 #define MFS_VM_SC(expr) ((T)1)
 #define MFS_VM_MK(expr) 0x01010101u
@@ -292,6 +330,10 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   const int tid = threadIdx.x;
   const int SU = vm_su<VEC>(Nz), BUF = 3 * SU;
   const int tile_elems = kVmBlock * VEC;
+#ifdef MFS_VM_STAMPS
+  unsigned long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
   for (int64_t i = s0; i < s1;) {
     const int tile = (int)(i / np);
@@ -372,6 +414,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       rg.eyzc = vload<T, VEC>(q + 3 * cs); rg.eyzyp = vload<T, VEC>(q + 3 * cs + MFS_VM_NBR(c.pz));
     }
     unsigned msk = MFS_VM_MK(vm_mask<VEC>(MP + (int64_t)x0 * sc + o_c));
+    MFS_VM_STAMP(0);                                             // prologue
 
     for (int x = x0; x < x1; ++x) {
       const int k = x - x0;
@@ -382,11 +425,13 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       // ---- (1) ONE barrier per plane: plane x+1's images (published at the end of the previous step) are complete,
       //      and nobody reads plane x-2's slot any more (it is written at the end of this step)
       MFS_VISC_LDS_BARRIER();
+      MFS_VM_STAMP(1);                                           // barrier
       // ---- (2) in flight for the whole step: own rows and halo vectors of plane x+2 (clamped at the end: unused)
       const Plane pn = fetch(min(x + 2, Nx - 1));
       const T* const qn = C1 + (int64_t)min(x + 1, Nx - 2) * sc + o_c;      // next step's class samples
       const unsigned char* const mqn = MP + (int64_t)min(x + 1, Nx - 2) * sc + o_c;
       MFS_VM_PIN();
+      MFS_VM_STAMP(2);                                           // issue of plane x+2's loads
       // ---- (3) u rows.  Every velocity operand comes from the images (the ring is the register file of the march:
       //      nothing velocity is carried across steps); the registers of the class samples only this phase reads take
       //      the next step's afterwards (a whole step in flight)
@@ -398,14 +443,17 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       rg.wc = vload<T, VEC>(bc + 2 * SU + lu); rg.wzr = ZR(rg.wc, bc + 2 * SU + lu);
       rg.wm = vload<T, VEC>(bm + 2 * SU + lu); rg.wmzr = ZR(rg.wm, bm + 2 * SU + lu);
       { const T t = vm_from_right<T>(rg.exzc[0]); rg.exzzr = fixr ? rg.exzzr : t; }      // EXZ[x, y, z0+VEC]
+      MFS_VM_STAMP(3);                                           // u: image reads (issued and landed)
       V qu;
       vm_row<T, VEC, 0>(rg, k1, k2, msk, qu, first, last, active, acc);
+      MFS_VM_STAMP(4);                                           // u: rows (includes the wait for this step's class samples)
       if (active) vm_store<T, VEC, true>(ox + (int64_t)x * su + o_uv, qu, first, last);
       MFS_VM_PIN();
       const V fxn = vload<T, VEC>(qn + 2 * cs), ccn = vload<T, VEC>(qn + 6 * cs), exyypn = vload<T, VEC>(qn + MFS_VM_NBR(c.pz));
       T exzzrn = (T)0;
       if (fixr) exzzrn = qn[cs + VEC];
       MFS_VM_PIN();
+      MFS_VM_STAMP(5);                                           // u: store + issue of the next step's samples
       // ---- (4) v rows
       rg.vc = vload<T, VEC>(bc + SU + lu); rg.vp = vload<T, VEC>(bn + SU + lu); rg.vm = vload<T, VEC>(bm + SU + lu);
       rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vym = vload<T, VEC>(bc + SU + lu - Nz);
@@ -420,8 +468,10 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
         rg.wym[VEC] = ZR(t, bc + 2 * SU + lu - Nz);
       }
       { const T t = vm_from_right<T>(rg.eyzc[0]); rg.eyzzr = fixr ? rg.eyzzr : t; }      // EYZ[x, y, z0+VEC]
+      MFS_VM_STAMP(6);                                           // v: image reads
       V qv;
       vm_row<T, VEC, 1>(rg, k1, k2, msk, qv, first, last, active, acc);
+      MFS_VM_STAMP(7);                                           // v: rows
       if (active) vm_store<T, VEC, true>(oy + (int64_t)x * sv + o_uv, qv, first, last);
       MFS_VM_PIN();
       const V fyn = vload<T, VEC>(qn + 4 * cs), cymn = vload<T, VEC>(qn + 6 * cs - MFS_VM_NBR(c.pz)), exypn = vload<T, VEC>(qn + sc);
@@ -429,6 +479,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       if (fixr) eyzzrn = qn[3 * cs + VEC];
       const unsigned mskn = MFS_VM_MK(vm_mask<VEC>(mqn));
       MFS_VM_PIN();
+      MFS_VM_STAMP(8);                                           // v: store + issue
       // ---- (5) w rows
       rg.wc = vload<T, VEC>(bc + 2 * SU + lu); rg.wp = vload<T, VEC>(bn + 2 * SU + lu); rg.wm = vload<T, VEC>(bm + 2 * SU + lu);
       rg.wyp = vload<T, VEC>(bc + 2 * SU + lu + Nz);
@@ -443,8 +494,10 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       rg.vc = vload<T, VEC>(bc + SU + lu); rg.vzl = ZL(rg.vc, bc + SU + lu);
       rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vypzl = ZL(rg.vyp, bc + SU + lu + Nz);
       { const T t = vm_from_left<T>(rg.cc[VEC - 1]); rg.czl = fixl ? rg.czl : t; }        // C[x, y, z0-1]
+      MFS_VM_STAMP(9);                                           // w: image reads
       V qw;
       vm_row<T, VEC, 2>(rg, k1, k2, msk, qw, first, last, active, acc);
+      MFS_VM_STAMP(10);                                          // w: rows
       if (active) vm_store<T, VEC, false>(oz + (int64_t)x * sw + o_w, qw, first, last);
       MFS_VM_PIN();
       const V fzn = vload<T, VEC>(qn + 5 * cs), exzpn = vload<T, VEC>(qn + cs + sc), eyzcn = vload<T, VEC>(qn + 3 * cs),
@@ -454,6 +507,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       MFS_VM_PIN();
       // ---- (6) plane x+2 into its slot (its loads have had the whole step); next step's class samples take over
       publish(bw, pn);
+      MFS_VM_STAMP(11);                                          // w: store + issue, publish of plane x+2 (waits for its loads)
       rg.cm = rg.cc; rg.cc = ccn;
       rg.exyc = rg.exyp; rg.exyp = exypn; rg.exzc = rg.exzp; rg.exzp = exzpn;
       rg.fx = fxn; rg.exyyp = exyypn; rg.exzzr = exzzrn;
@@ -463,6 +517,12 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     }
     MFS_VISC_LDS_BARRIER();      // the next march stages into the ring while a slow wave may still read this one's planes
   }
+#ifdef MFS_VM_STAMPS
+  if (blockIdx.x < 64 && (tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) partial[4096 + (blockIdx.x * 4 + tid / 64) * 12 + k] = (double)stamp_sum[k];
+  }
+#endif
   const double tot = block_sum<kVmBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }

@@ -41,3 +41,28 @@ def test_c_cg_fixed_iterations_matches_numpy_oracle():
     np.testing.assert_allclose(res["history"], np.array(hist), rtol=1e-11)
     np.testing.assert_allclose(res["x"], x, rtol=0, atol=1e-12 * np.abs(x).max())
     assert CB.threads() >= 1
+
+
+@pytest.mark.parametrize("name", golden_names("v3d_"))
+def test_c_viscosity_apply_and_cg_vs_golden(name):
+    """the C restatement of the viscosity operator and CG loop against the executed-reference goldens"""
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    cell_vol = float(np.prod(g["bound_size"] / g["gres"]))
+    scale, mu = float(g["dt"]) / cell_vol / float(g["rho"]), float(g["mu"])
+    vol = g["lvol"] / (cell_vol * 0.125)
+    q = [np.full(g[k].shape, 7.0) for k in ("qx", "qy", "qz")]
+    CB.visc_apply(gres, scale, mu, g["ex"], g["ey"], g["ez"], *q, g["sphi"], vol)
+    for got, k in zip(q, ("qx", "qy", "qz")):
+        np.testing.assert_allclose(got, g[k], rtol=1e-13, atol=1e-13 * np.abs(g[k]).max())   # incl. the untouched 7s
+    b = np.concatenate([g[k].ravel() for k in ("bx", "by", "bz")])
+    x0 = np.concatenate([g[k].ravel() for k in ("ex", "ey", "ez")])
+    res = CB.visc_cg(gres, scale, mu, b, x0, g["sphi"], vol, float(g["tol"]), int(np.prod(gres)), 4096)
+    assert res["converged"]
+    h, hg = res["history"], g["history"]
+    n = min(21, len(h), len(hg))
+    np.testing.assert_allclose(h[:n], hg[:n], rtol=1e-10)
+    assert abs(res["iterations"] - int(g["iters"])) <= max(2, int(g["iters"]) // 10)
+    xg = np.concatenate([g[k].ravel() for k in ("x_x", "x_y", "x_z")])
+    # converged field: 1e-4 of the field maximum, as everywhere (the history is rounding-chaotic past its leading window)
+    np.testing.assert_allclose(res["x"], xg, rtol=0, atol=1e-4 * np.abs(xg).max())
