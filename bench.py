@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-line", action="store_true", help="skip the fp64-state sub-measurement (default precision of the drop-in)")
+    ap.add_argument("--timed-loop-only", action="store_true",
+                    help="profiling runs (tools/pmc_bench.sh): warm-up + timed loop only -- no roofline legs, no parity self-check, "
+                         "no fp64 line -- so that per-kernel counter averages belong to ONE configuration")
+    ap.add_argument("--dense-coefficients", action="store_true", help="timed loop with compressed coefficient access off")
+    ap.add_argument("--unfused", action="store_true", help="timed loop with the direction update as its own kernel")
     ap.add_argument("--force-phases", action="store_true",
                     help="1 GPU: run the phase-by-phase multi-GPU driver loop (1-rank RCCL group) to price its host overhead")
     ap.add_argument("--transport", default="auto", choices=["auto", "p2p", "rccl"],
@@ -247,6 +252,10 @@ def main():
     eng = PcgEngine(lgres, tdt, dev)
     eng.setup(lphi, wx, wy, wz)
     eng.bind(b, x, d, r, q)
+    if args.dense_coefficients:
+        eng.set_compress(False)
+    if args.unfused:
+        eng.set_fuse(False)
     multi = world > 1 or args.force_phases or args.force_p2p
     cg_rccl = mdist.SlabCG(eng, part, d, dist if multi else None, force_multi=args.force_phases or args.force_p2p)
     cg, transport, tinfo = cg_rccl, ("rccl" if multi else "single"), {}
@@ -381,10 +390,11 @@ def main():
     rf = None
     parity = None
     f64_line = None
-    if rank == 0:
+    if rank == 0 and not args.timed_loop_only:
         Nx, Ny, Nz = lgres
         cells_l = Nx * Ny * Nz
         reps = max(20, min(args.steps, 200))
+        reps_leg = 24          # the side legs stay short: they share kernel templates with the timed loop (rocprof averages)
 
         def time_apply(engine, n):
             """average duration of the stencil launch inside real CG iterations: HIP events (on the stream the kernel is
@@ -410,7 +420,7 @@ def main():
             engine.begin(0.0)
             engine.iterate(2)
             form = engine.loop_info()
-            ms = time_apply(engine, reps)
+            ms = time_apply(engine, reps_leg)
             ab = alg_bytes_of(form, fused)
             return {"kernel": label, "algorithmic_bytes": ab, "kernel_ms": round(ms, 5),
                     "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_$C -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_$C -- python3 $R/bench.py --no-cpu-baseline --timed-loop-only "$@" > $R/gpurun_out/${TAG}_$C.log 2>&1
 done
 python3 - $R/gpurun_out/${TAG} > $R/gpurun_out/${TAG}_summary.json <<'PY'
 import csv, glob, json, sys, collections
