@@ -419,3 +419,190 @@ class SlabVCG(_BoundedCollectives):
                 self.drain()
             st = self.ops.poll()
         return bool(st["done"]), int(st["iterations"])
+
+
+class SlabBands:
+    """Plane-band exchanges for fields kept as GLOBAL-shaped arrays of which every rank maintains only its own x-range
+    (the particle-sharded time step, notebook_sim.ShardedNotebookSimulation): no whole-grid collective, only the
+    planes near the cuts travel.
+
+    Ownership: the cell planes [0, Nx) are cut at the slab partition's cuts (`SlabPartition.owned`; the two array-
+    boundary planes 0 and Nx-1 go to the first / last rank).  An array's `kind` says how its axis 0 relates to cells:
+    "cell" (Nx planes), "xface" (Nx+1: face i belongs to the owner of cell i, the last face to the last rank) or
+    "doubled" (2Nx+1 nodes: nodes 2i, 2i+1 belong to the owner of cell i, the last node to the last rank).
+
+      reduce(arrs, kind, reach, op): every rank has scattered its own particles' contributions, up to `reach` cells
+          beyond its range; the contributions on planes another rank owns are sent there and combined (op "sum" | "min").
+      ghosts(arrs, kind, width): every rank receives the owners' values of the planes up to `width` cells beyond its range.
+
+    Bands may span more than one neighbour (thin slabs): a rank talks to every rank that owns planes of its band.
+    P2P sends / receives of contiguous plane ranges (RCCL moves device memory; any other backend gets host copies);
+    waits are bounded like every collective wait of this module."""
+
+    def __init__(self, dist, group, nx, device=None):
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.nx = int(nx)
+        self.part = SlabPartition(nx, self.world, self.rank)
+        self.cuts = [0] + [SlabPartition(nx, self.world, r).owned[0] for r in range(1, self.world)] + [self.nx]
+        self.timeout_s = collective_timeout_s()
+        self.bytes_moved = 0
+
+    def cells(self, r=None):
+        r = self.rank if r is None else r
+        return self.cuts[r], self.cuts[r + 1]
+
+    def owned(self, kind, r=None):
+        r = self.rank if r is None else r
+        a, b = self.cells(r)
+        last = r == self.world - 1
+        if kind == "cell":
+            return a, b
+        if kind == "xface":
+            return a, b + (1 if last else 0)
+        if kind == "doubled":
+            return 2 * a, 2 * b + (1 if last else 0)
+        raise ValueError(kind)
+
+    def _band(self, kind, width, r):
+        """the planes up to `width` cells beyond rank r's range, as (lo band, hi band), clipped to the array"""
+        a, b = self.owned(kind, r)
+        w = width * (2 if kind == "doubled" else 1)
+        n = {"cell": self.nx, "xface": self.nx + 1, "doubled": 2 * self.nx + 1}[kind]
+        return (max(0, a - w), a), (b, min(n, b + w))
+
+    @staticmethod
+    def _cut(r0, r1):
+        lo, hi = max(r0[0], r1[0]), min(r0[1], r1[1])
+        return (lo, hi) if hi > lo else None
+
+    def _plan(self, kind, width, mine_is_band):
+        """[(peer, send range, recv range)]: mine_is_band -> I SEND my band planes the peer owns and RECEIVE the peer's
+        band planes I own (reduce); else I send my owned planes in the peer's band and receive its owned planes in mine"""
+        plan = []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            send = recv = None
+            for mb, qb in zip(self._band(kind, width, self.rank), self._band(kind, width, q)):
+                if mine_is_band:
+                    s, rcv = self._cut(mb, self.owned(kind, q)), self._cut(qb, self.owned(kind))
+                else:
+                    s, rcv = self._cut(self.owned(kind), qb), self._cut(self.owned(kind, q), mb)
+                send = send or s
+                recv = recv or rcv
+            if send or recv:
+                plan.append((q, send, recv))
+        return plan
+
+    def _run(self, ops_send, ops_recv):
+        """ops_send: [(tensor view, peer)], ops_recv: [(buffer, peer)]; completes them all (bounded)"""
+        dist = self.dist
+        if not ops_send and not ops_recv:
+            return
+        staged = any(getattr(t, "is_cuda", False) for t, _ in ops_send + ops_recv) and dist.get_backend(self.group) != "nccl"
+        sends = [(t.cpu() if staged else t.contiguous(), q) for t, q in ops_send]
+        recvs = [((torch_empty_like_cpu(t) if staged else t), q, t) for t, q in ops_recv]
+        ops = [dist.P2POp(dist.isend, t, q, self.group) for t, q in sends]
+        ops += [dist.P2POp(dist.irecv, t, q, self.group) for t, q, _ in recvs]
+        import datetime as _dt
+        for w in dist.batch_isend_irecv(ops):
+            try:
+                ok = w.wait(timeout=_dt.timedelta(seconds=self.timeout_s)) if dist.get_backend(self.group) != "nccl" else w.wait()
+            except RuntimeError as exc:
+                raise _lib.MfsTimeout(f"band exchange failed with status {_lib.MFS_E_TIMEOUT}: wait timed out on rank "
+                                      f"{self.rank} [{type(exc).__name__}: {str(exc)[:160]}]") from None
+            if ok is False:
+                raise _lib.MfsTimeout(f"band exchange failed with status {_lib.MFS_E_TIMEOUT}: wait timed out on rank {self.rank}")
+        if staged:
+            for buf, _, dst in recvs:
+                dst.copy_(buf)
+        self.bytes_moved += sum(t.numel() * t.element_size() for t, _ in ops_send)
+
+    def reduce(self, arrs, kind, reach, op="sum"):
+        if self.world == 1:
+            return
+        plan = self._plan(kind, reach, True)
+        sends, recvs, combine = [], [], []
+        for arr in arrs:
+            for q, s, r in plan:
+                if s:
+                    sends.append((arr[s[0]:s[1]], q))
+                if r:
+                    buf = arr.new_empty((r[1] - r[0],) + tuple(arr.shape[1:]))
+                    recvs.append((buf, q))
+                    combine.append((arr, r, buf))
+        self._run(sends, recvs)
+        for arr, r, buf in combine:
+            dst = arr[r[0]:r[1]]
+            if op == "sum":
+                dst.add_(buf)
+            elif op == "min":
+                import torch
+                torch.minimum(dst, buf, out=dst)
+            else:
+                raise ValueError(op)
+
+    def ghosts(self, arrs, kind, width):
+        if self.world == 1:
+            return
+        plan = self._plan(kind, width, False)
+        sends, recvs = [], []
+        for arr in arrs:
+            for q, s, r in plan:
+                if s:
+                    sends.append((arr[s[0]:s[1]], q))
+                if r:
+                    recvs.append((arr[r[0]:r[1]], q))
+        self._run(sends, recvs)
+
+    def owner_of_cells(self, ix):
+        """rank owning cell plane ix (tensor of int64 cell indices, clamped to the grid)"""
+        import torch
+        cuts = torch.as_tensor(self.cuts[1:-1], dtype=ix.dtype, device=ix.device)
+        return torch.bucketize(ix.clamp(0, self.nx - 1), cuts, right=True)
+
+    def migrate(self, fields, dest):
+        """particles change owner: `fields` = list of per-particle tensors (same length P), `dest` = destination rank of
+        each particle.  Returns the list of tensors after the exchange (kept particles first, then arrivals in rank
+        order).  One count exchange + one packed payload per peer pair."""
+        import torch
+        dist, me, W = self.dist, self.rank, self.world
+        if W == 1:
+            return fields
+        keep = dest == me
+        counts = torch.bincount(dest, minlength=W).to(torch.int64).cpu()
+        allc = [torch.zeros(W, dtype=torch.int64) for _ in range(W)]
+        dist.all_gather(allc, counts, group=self.group)             # allc[q][r] = particles q sends to r
+        widths = []
+        for f in fields:
+            w = 1
+            for s_ in f.shape[1:]:
+                w *= int(s_)
+            widths.append(w)
+        dev = fields[0].device
+        packed = torch.cat([f.reshape(f.shape[0], w).to(torch.float64) for f, w in zip(fields, widths)], dim=1)   # ids ride as exact doubles
+        sends, recvs, bufs = [], [], []
+        for q in range(W):
+            if q == me:
+                continue
+            ns, nr = int(counts[q]), int(allc[q][me])
+            if ns:
+                sends.append((packed[dest == q].contiguous(), q))
+            if nr:
+                b = torch.empty((nr, packed.shape[1]), dtype=torch.float64, device=dev)
+                recvs.append((b, q))
+                bufs.append(b)
+        self._run(sends, recvs)
+        out = torch.cat([packed[keep]] + bufs, dim=0) if bufs else packed[keep]
+        res, o = [], 0
+        for f, w in zip(fields, widths):
+            col = out[:, o:o + w]
+            o += w
+            res.append(col.reshape((out.shape[0],) + tuple(f.shape[1:])).to(f.dtype).contiguous())
+        return res
+
+
+def torch_empty_like_cpu(t):
+    import torch
+    return torch.empty(tuple(t.shape), dtype=t.dtype, device="cpu")

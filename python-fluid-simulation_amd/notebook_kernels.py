@@ -89,6 +89,32 @@ def p2g(p, g):
                    "mfs_p2g_normalize3d")
 
 
+def p2g_scatter(p, g):
+    """the scatter half of `p2g` alone (particle-sharded time step: the ranks' shares are added before the division)"""
+    gres = T.as_gres(g.resolution)
+    px, pv = _particles(p.x, "p.x"), _particles(p.v, "p.v")
+    pm = T.dev(p.m, "p.m", (px.shape[0],))
+    lib = _lib.load()
+    if px.shape[0] == 0:
+        return
+    for gc, pc, axis in ((g.x, p.cx, 0), (g.y, p.cy, 1), (g.z, p.cz, 2)):
+        pc = _particles(pc, "p.c" + "xyz"[axis])
+        gm = T.dev(gc.m, "g.%s.m" % "xyz"[axis], T.face_shape(gres, axis))
+        gv = T.dev(gc.v, "g.%s.v" % "xyz"[axis], T.face_shape(gres, axis))
+        _lib.check(lib.mfs_p2g_scatter3d(_lib.i64x(gres), _f3(g.bound_min), _f3(g.cell_size), _f3(gc.bias), axis,
+                                         T.ptr(px), T.code(px), T.ptr(pm), T.code(pm), T.ptr(pv), T.code(pv), T.ptr(pc),
+                                         T.code(pc), int(px.shape[0]), T.ptr(gm), T.ptr(gv), T.code(gm), T.stream()),
+                   "mfs_p2g_scatter3d")
+
+
+def p2g_normalize(g):
+    """the division half of `p2g`: momentum / mass where mass landed"""
+    lib = _lib.load()
+    for gc in (g.x, g.y, g.z):
+        _lib.check(lib.mfs_p2g_normalize3d(int(gc.m.numel()), T.ptr(gc.m), T.ptr(gc.v), T.code(gc.m), T.stream()),
+                   "mfs_p2g_normalize3d")
+
+
 def g2p(p, g):
     """Grid -> particle (code cell 3): p.v[:, axis] and the affine rows p.cx / p.cy / p.cz from g.*.v."""
     gres = T.as_gres(g.resolution)

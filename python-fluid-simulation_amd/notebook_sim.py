@@ -204,6 +204,140 @@ class SlabNotebookSimulation(NotebookSimulation):
         self.ViscositySolver.close()
 
 
+class ShardedNotebookSimulation(SlabNotebookSimulation):
+    """BASELINE config 5 with the PARTICLES sharded as well: one process per GPU, rank r owns the particles whose cell
+    lies in its x-range (`mfs.dist.SlabBands`: the slab partition's cuts) and maintains every grid field on its own
+    planes plus a band of ghost planes; no stage touches a whole grid over the wire.
+
+      advect + project      own particles; those that left the range MIGRATE to their new owner (ids travel with them)
+      level set / volume    atomic-min / trilinear splat of the own particles; contributions beyond the range go to their
+                            owners (band reduce, min / sum), ghost planes come back from the owners
+      density solve         `SlabDensityCGSolver3D.solve_sharded` (splat -> band reduce; CG slab-decomposed; displacement)
+      p2g                   scatter of mass and momentum -> band reduce -> normalise -> ghosts
+      viscosity, pressure   slab-decomposed CG on views of this rank's planes (as in SlabNotebookSimulation)
+      extrapolate, BC, g2p  grid stencils on the range + ghost band (their reach, summed, is the band width), gather by
+                            the own particles
+    The constructor takes the FULL initial particle set (every rank builds the scene identically) and keeps the own
+    share; `gather_particles()` assembles (id, x, v) over the ranks for inspection.  `step` is collective."""
+
+    GHOST, REACH = 4, 3        # cells: ghost band maintained around the range; scatter reach (5^3 level-set stencil + slack)
+
+    def __init__(self, *args, dist, group=None, transport="auto", **kw):
+        super().__init__(*args, dist=dist, group=group, transport=transport, **kw)
+        from mfs.dist import SlabBands
+        self.bands = SlabBands(dist, group, self.GRES[0])
+        p = self.particle
+        p.id = torch.arange(p.num_particles, dtype=torch.int64, device=self.device)
+        self.total_particles = p.num_particles
+        own = self.bands.owner_of_cells(self._cell_x(p.x)) == self.rank      # every rank built the full set: keep the own share
+        p.x, p.v, p.cx, p.cy, p.cz, p.m, p.id = (t[own].contiguous() for t in (p.x, p.v, p.cx, p.cy, p.cz, p.m, p.id))
+        p.num_particles = int(p.x.shape[0])
+
+    def set_particle_velocities(self, v_all):
+        """initial velocities given for the FULL particle set (indexed by particle id)"""
+        v_all = torch.as_tensor(v_all, dtype=torch.float64, device=self.device)
+        self.particle.v.copy_(v_all[self.particle.id])
+
+    def _cell_x(self, px):
+        g = self.grid
+        t = (px[:, 0].to(torch.float32) - float(g.bound_min[0])).to(torch.float64) / float(g.cell_size[0])
+        return torch.floor(t).to(torch.int64)
+
+    def _migrate(self):
+        p = self.particle
+        dest = self.bands.owner_of_cells(self._cell_x(p.x))
+        fields = [p.x, p.v, p.cx, p.cy, p.cz, p.m, p.id]
+        p.x, p.v, p.cx, p.cy, p.cz, p.m, p.id = self.bands.migrate(fields, dest)
+        p.num_particles = int(p.x.shape[0])
+
+    def gather_particles(self):
+        """(id, x, v) of all particles, sorted by id, on every rank (inspection / tests: a whole-set collective)"""
+        p, dist = self.particle, self.dist
+        n = torch.tensor([p.num_particles], dtype=torch.int64)
+        ns = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(ns, n, group=self.group)
+        mine = torch.cat([p.id.to(torch.float64)[:, None], p.x, p.v], dim=1).cpu()
+        parts = []
+        for r in range(self.world):
+            buf = mine if r == self.rank else torch.empty((int(ns[r]), 7), dtype=torch.float64)
+            dist.broadcast(buf, src=r, group=self.group)
+            parts.append(buf)
+        allp = torch.cat(parts, dim=0)
+        allp = allp[torch.argsort(allp[:, 0])]
+        return allp[:, 0].to(torch.int64), allp[:, 1:4], allp[:, 4:7], [int(v) for v in ns]
+
+    def step(self, duration_left=float("inf"), timings=None):
+        p, g, sl, fl, fv = self.particle, self.grid, self.solid_levelset, self.fluid_levelset, self.fluid_volume
+        B, W, R, dist = self.bands, self.GHOST, self.REACH, self.dist
+
+        def tick(name, t0):
+            if timings is not None:
+                torch.cuda.synchronize()
+                timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+
+        def levelset_and_volume():
+            K.compute_fluid_levelset(p, fl, self.GDX)
+            B.reduce([fl.phi], "cell", R, "min")
+            B.ghosts([fl.phi], "cell", W)
+            K.compute_fluid_volume(p, fv, p.vol)            # splat + clamp of the own particles' share ...
+            B.reduce([fv.vol], "doubled", R, "sum")         # ... non-negative shares: clamp(sum of clamped) == clamp(sum)
+            fv.vol.clamp_(max=float(np.prod(fv.cell_size)))
+            B.ghosts([fv.vol], "doubled", W)
+
+        t = time.perf_counter()
+        vloc = torch.sqrt((p.v ** 2).sum(dim=-1)).max().item() if p.num_particles else 0.0
+        vm = torch.tensor([vloc], dtype=torch.float64)
+        dist.all_reduce(vm, op=dist.ReduceOp.MAX, group=self.group)
+        cfl_dt = self.GDX / max(1e-10, vm.item())
+        dt = min(self.DT, cfl_dt, duration_left)
+        self.current_time += dt
+        p.x += p.v * dt
+        sdf.project(self.rb_d, p.x)
+        self._migrate()
+        t = tick("advect+project+migrate", t)
+        levelset_and_volume()
+        t = tick("levelset+volume", t)
+        self.DensitySolver.solve_sharded(B, self.RHO, dt, p.x, p.m, p.vol, sl.phi, sl.v, fl.phi, fv.vol, reach=R, width=W)
+        self._migrate()                                      # the displacement moved particles
+        t = tick("density", t)
+        levelset_and_volume()
+        t = tick("levelset+volume", t)
+        comps = (g.x, g.y, g.z)
+        for c in comps:
+            c.m.zero_()
+            c.v.zero_()
+        K.p2g_scatter(p, g)
+        B.reduce([g.x.m, g.x.v], "xface", R, "sum")
+        B.reduce([g.y.m, g.y.v, g.z.m, g.z.v], "cell", R, "sum")
+        K.p2g_normalize(g)
+        B.ghosts([g.x.m, g.x.v], "xface", W)
+        B.ghosts([g.y.m, g.y.v, g.z.m, g.z.v], "cell", W)
+        g.y.v += -10 * dt                                                   # gravity
+        t = tick("p2g", t)
+        # the two hot-path solves on views of this rank's planes (one ghost / boundary plane each side)
+        ds = self.DensitySolver
+        lo, hi = self.part.local_range
+        vx, vy, vz = g.x.v[lo:hi + 1], g.y.v[lo:hi], g.z.v[lo:hi]
+        sphi, sv, lphi = sl.phi[2 * lo:2 * hi + 1], sl.v[2 * lo:2 * hi + 1], fl.phi[lo:hi]
+        if self.MU > 0:
+            self.ViscositySolver.solve(dt, self.MU, self.RHO, vx, vy, vz, sphi, sv, lphi, fv.vol[2 * lo:2 * hi + 1])
+            B.ghosts([g.x.v], "xface", W)                    # the pressure RHS reads the ghost planes' faces
+            B.ghosts([g.y.v, g.z.v], "cell", W)
+        t = tick("viscosity", t)
+        self.PressureSolver.solve(vx, vy, vz, sphi, sv, lphi, wx=ds.wx[lo:hi + 1], wy=ds.wy[lo:hi], wz=ds.wz[lo:hi])
+        B.ghosts([g.x.v], "xface", W)
+        B.ghosts([g.y.v, g.z.v], "cell", W)
+        t = tick("pressure", t)
+        K.extrapolate(self.GRES, 2, g.x.v, g.y.v, g.z.v, g.x.m, g.y.m, g.z.m)
+        K.apply_boundary_condition(g, sl, self.GDX)
+        t = tick("extrapolate+bc", t)
+        K.g2p(p, g)
+        tick("g2p", t)
+        self.iterations += 1
+        return dt
+
+
 def add_box(center, size, dx, rng, keep=None):
     """Particle seeding of code cell 9 (`add_box`): a jittered lattice of spacing dx filling a box."""
     center, size = np.asarray(center, np.float64), np.asarray(size, np.float64)

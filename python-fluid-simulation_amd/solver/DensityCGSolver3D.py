@@ -253,3 +253,46 @@ class SlabDensityCGSolver3D(DensityCGSolver3D):
             apply_displacement(px, self.dx, self.bound_min, self.cell_size, self.bias_x, 0)
             apply_displacement(px, self.dy, self.bound_min, self.cell_size, self.bias_y, 1)
             apply_displacement(px, self.dz, self.bound_min, self.cell_size, self.bias_z, 2)
+
+
+    def solve_sharded(self, bands, rho0, dt, px, pm, pvol, sphi, sv, lphi, lvol, wx=None, wy=None, wz=None, tol=1e-3,
+                      reach=3, width=4):
+        """The same solve with the particles SHARDED: `px`, `pm` are this rank's own particles (those in its x-range,
+        `bands`: mfs.dist.SlabBands); every global-shaped array is maintained on this rank's planes plus `width` ghost
+        planes only.  The splat's contributions beyond the range go to their owners (band reduce), the CG loop runs on
+        the slab as in `solve`, the solution's ghost planes come from their owners, and the displacement moves the own
+        particles.  No whole-grid collective.  Collective."""
+        g = self._g
+        if wx is None or wy is None or wz is None:
+            compute_solid_frac(self.gres, sphi, self.wx, self.wy, self.wz)       # static scene data: every rank, whole grid
+            wx, wy, wz = self.wx, self.wy, self.wz
+        eng = self._engine
+        lo, hi = self.part.local_range
+        lphi = T.dev(lphi, "lphi", g)
+        wx, wy, wz = _faces(g, wx, wy, wz)
+        with torch.cuda.device(self.x.device):
+            self.m *= 0
+            self.vol *= 0
+            initialize_density(self.bound_min, self.cell_size, g, px, pm, pvol, self.m, self.vol, sphi, lphi)
+            bands.reduce([self.m, self.vol], "cell", reach, "sum")
+            bands.ghosts([self.m, self.vol], "cell", width)
+            fix_volume(self.cell_size, g, lvol, self.vol, sphi, lphi, wx, wy, wz)
+            initialize_solver(rho0, dt, g, self.cell_size, self.m, self.vol, lphi, wx, wy, wz, self.buf.b)
+            self._lb.copy_(self.buf.b[lo:hi])
+            self._lb[0].zero_()          # ghost / boundary planes carry no equation on this rank
+            self._lb[-1].zero_()
+            eng.setup_density(lphi[lo:hi], wx[lo:hi + 1], wy[lo:hi], wz[lo:hi])
+            eng.bind(self._lb, self._lx, self._ld, self._lr, self._lq)
+            ok, self.iterations = self._cg.solve(tol, self.max_iter, self.check_every)
+            self.transport = "p2p" if getattr(self._cg, "_p2p_active", False) else "rccl"
+            st = eng.poll()
+            self.alpha, self.beta, self.delta = st["alpha"], st["beta"], st["delta"]
+            if not ok:
+                raise ValueError("Failed to converge!")
+            self.x.zero_()
+            self.x[lo + 1:hi - 1] = self._lx[1:-1]
+            bands.ghosts([self.x], "cell", width)
+            compute_displacement(g, dt, self.cell_size, self.dx, self.dy, self.dz, self.x, lphi)
+            apply_displacement(px, self.dx, self.bound_min, self.cell_size, self.bias_x, 0)
+            apply_displacement(px, self.dy, self.bound_min, self.cell_size, self.bias_y, 1)
+            apply_displacement(px, self.dz, self.bound_min, self.cell_size, self.bias_z, 2)

@@ -112,6 +112,38 @@ def timestep_mode(rank, world, path, out, dtname, dev):
     sim.close()
 
 
+def timestep_sharded_mode(rank, world, path, out, dtname, dev):
+    """ShardedNotebookSimulation: whole time steps with the particles sharded by x-slab as well (BASELINE config 5)."""
+    import notebook_sim as NSIM
+    import solver.sdf3D as sdf
+    with np.load(path, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    gres = tuple(int(v) for v in g["gres"])
+    gdx = float(g["gdx"])
+    size = np.array(gres) * gdx
+    rb_d, rb_map = sdf.generate_rb(None, {}, 'cube', ['box', size[0] - 2 * gdx, size[1] - 2 * gdx, size[2] - 2 * gdx], flip=True,
+                                   center=[0, size[1] / 2, 0], axis=[0., 1, 0], angle=0, device=dev)
+    rb_d, rb_map = sdf.generate_rb(rb_d, rb_map, 'ramp', ['box', 0.45, 0.05, 0.8], flip=False, center=[-0.12, 0.2, 0],
+                                   axis=[0., 0, 1], angle=-35)
+    sim = NSIM.ShardedNotebookSimulation(gres, gdx, [-0.3, 0, -0.3], rb_d, g["px0"], float(g["pdx"]), rho=float(g["rho"]),
+                                         mu=float(g["mu"]), dt=float(g["dt"]), device=dev, dist=dist,
+                                         transport=os.environ.get("P2P_TEST_TRANSPORT", "auto"))
+    sim.set_particle_velocities(g["pv0"])
+    res, timings = {}, {}
+    for s in range(int(g["steps"])):
+        res[f"dt{s + 1}"] = sim.step(timings=timings)
+        ids, x, v, counts = sim.gather_particles()
+        assert ids.numpy().tolist() == list(range(sim.total_particles)), "a particle was lost or duplicated in migration"
+        res[f"px{s + 1}"], res[f"pv{s + 1}"], res[f"counts{s + 1}"] = x.numpy(), v.numpy(), np.array(counts)
+        res[f"lphi{s + 1}"] = sim.fluid_levelset.phi.cpu().numpy()       # valid on this rank's planes (+ ghosts)
+        res[f"gvy{s + 1}"] = sim.grid.y.v.cpu().numpy()
+    a, b = sim.bands.owned("cell")
+    np.savez(f"{out}.rank{rank}.npz", transport=sim.PressureSolver.transport, p_iters=sim.PressureSolver.iterations,
+             v_iters=sim.ViscositySolver.iterations, d_iters=sim.DensitySolver.iterations, stages=np.array(sorted(timings)),
+             own_lo=a, own_hi=b, band_bytes=sim.bands.bytes_moved, **res)
+    sim.close()
+
+
 def _close_after_fault(win):
     """teardown of the fault-injection modes: the group may be broken by the timed-out collective (gloo closes the
     pair), so the window's closing barrier is best-effort and the process leaves without a collective teardown."""
@@ -198,6 +230,12 @@ def main():
     if os.environ.get("P2P_TEST_MODE") == "density":
         try:
             density_mode(rank, world, path, out, dtname, dev)
+        finally:
+            dist.destroy_process_group()
+        return
+    if os.environ.get("P2P_TEST_MODE") == "timestep_sharded":
+        try:
+            timestep_sharded_mode(rank, world, path, out, dtname, dev)
         finally:
             dist.destroy_process_group()
         return

@@ -78,3 +78,38 @@ def test_two_full_steps_slab_decomposed(world, tmp_path):
     for r in res[1:]:       # the gathered grid velocities are the same arrays on every rank
         for s in range(int(g["steps"])):
             np.testing.assert_array_equal(r[f"gvy{s + 1}"], res[0][f"gvy{s + 1}"])
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_two_full_steps_particles_sharded(world, tmp_path):
+    """BASELINE config 5 with the particle stages sharded too (notebook_sim.ShardedNotebookSimulation): every rank owns
+    the particles of its x-range, scatters / gathers only them, and exchanges plane BANDS (no whole-grid collective).
+    Against the executed-reference goldens with the single-GPU tolerances: particles gathered by id, grid fields
+    assembled from the ranks' own planes; the per-rank particle counts sum to the total; nothing is lost in migration."""
+    from test_p2p_gpu import _run_ranks
+    g = golden("step_a_12x16x12")
+    res = _run_ranks("step_a_12x16x12", world, tmp_path, "f64", P2P_TEST_MODE="timestep_sharded")
+    total = g["px0"].shape[0]
+    cuts = sorted((int(r["own_lo"]), int(r["own_hi"])) for r in res)
+    assert cuts[0][0] == 0 and cuts[-1][1] == int(g["gres"][0]) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    for s in range(int(g["steps"])):
+        move = np.abs(g[f"px{s + 1}"] - g["px0"]).max()
+        lphi = np.zeros_like(g[f"lphi{s + 1}"])
+        gvy = np.zeros_like(g[f"gvy{s + 1}"])
+        for r in res:
+            assert float(r[f"dt{s + 1}"]) == pytest.approx(float(g["dts"][s]), rel=1e-12)
+            assert int(r[f"counts{s + 1}"].sum()) == total
+            np.testing.assert_allclose(r[f"px{s + 1}"], g[f"px{s + 1}"], rtol=0, atol=1e-4 * move * (s + 1))
+            np.testing.assert_allclose(r[f"pv{s + 1}"], g[f"pv{s + 1}"], rtol=0, atol=2e-3 * np.abs(g[f"pv{s + 1}"]).max())
+            a, b = int(r["own_lo"]), int(r["own_hi"])
+            lphi[a:b] = r[f"lphi{s + 1}"][a:b]
+            gvy[a:b] = r[f"gvy{s + 1}"][a:b]
+        np.testing.assert_allclose(lphi, g[f"lphi{s + 1}"], rtol=0, atol=1e-4 * float(g["gdx"]))
+        want = g[f"gvy{s + 1}"]
+        np.testing.assert_allclose(gvy, want, rtol=0, atol=5e-3 * np.abs(want).max())
+    for r in res:
+        assert int(r["p_iters"]) > 0 and int(r["v_iters"]) > 0 and int(r["d_iters"]) > 0
+        if world > 1:
+            assert int(r["band_bytes"]) > 0
+    if world > 1:      # more than one rank really holds particles
+        assert (res[0]["counts2"] > 0).sum() >= 2, res[0]["counts2"]
