@@ -22,9 +22,11 @@ if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if shared:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from mfs.dist import pg_timeout
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout())
     else:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        from mfs.dist import pg_timeout
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev), timeout=pg_timeout())
 gdx = 1.0 / N
 size = np.array([1.0, 1.0, 1.0])
 bmin = [-0.5, 0.0, -0.5]
@@ -39,8 +41,9 @@ px = NSIM.add_box([0.0, 0.7, 0.0], [0.5, 0.5, 0.5], gdx / 2, rng)
 if dist is None:
     sim = NSIM.NotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"))
 else:
-    sim = NSIM.SlabNotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev,
-                                      precision=os.environ.get("MFS_PRECISION"), dist=dist)
+    # MFS_TIMESTEP_PARTICLES=replicated: the round-1 form (every rank holds all particles, whole-grid broadcasts)
+    cls = NSIM.SlabNotebookSimulation if os.environ.get("MFS_TIMESTEP_PARTICLES") == "replicated" else NSIM.ShardedNotebookSimulation
+    sim = cls((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"), dist=dist)
 sim.particle.v[:, 0] = -2.0
 torch.cuda.synchronize()
 t_setup = time.perf_counter() - t0
@@ -57,9 +60,11 @@ if dist is not None:
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t_all = tt.item()
 if rank == 0:
-  print(json.dumps({"workload": f"notebook time step {N}^3, {sim.particle.num_particles} particles, mu={mu}",
+  print(json.dumps({"workload": f"notebook time step {N}^3, {getattr(sim, 'total_particles', sim.particle.num_particles)} particles, mu={mu}",
                   "ranks": world, "decomposition": "single GPU" if dist is None else
-                  f"density, viscosity and pressure CG loops on x-slabs x{world} (transports {sim.DensitySolver.transport}/{sim.ViscositySolver.transport}/{sim.PressureSolver.transport}), particle stages replicated"
+                  f"density, viscosity and pressure CG loops on x-slabs x{world} (transports {sim.DensitySolver.transport}/{sim.ViscositySolver.transport}/{sim.PressureSolver.transport}), particle stages "
+                  + ("sharded by x-slab: this rank holds %d of %d particles, %.1f MB of plane bands moved" % (sim.particle.num_particles, sim.total_particles, sim.bands.bytes_moved / 1e6)
+                     if hasattr(sim, "bands") else "replicated")
                   + (" [REHEARSAL: ranks share one GPU]" if shared else ""),
                   "state_precision": os.environ.get("MFS_PRECISION", "fp64"), "steps": steps,
                   "s_per_step": round(t_all / steps, 4), "setup_s": round(t_setup, 2),
