@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--local-grid", default="", help="1 GPU experiments: Nx,Ny,Nz of the grid (e.g. 66,512,512 = one rank's slab of the 8-GPU run)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-numpy-leg", action="store_true", help="CPU baseline: skip the 2-iteration numpy sample")
     ap.add_argument("--no-f64-line", action="store_true", help="skip the fp64-state sub-measurement (default precision of the drop-in)")
     ap.add_argument("--timed-loop-only", action="store_true",
                     help="profiling runs (tools/pmc_bench.sh): warm-up + timed loop only -- no roofline legs, no parity self-check, "
@@ -94,8 +95,19 @@ def cpu_baseline(args, gres, scene_seed):
         dt = time.perf_counter() - t0
         cores = 1
         sample = f"{iters} CG iterations of the same {Nx}x{Ny}x{Nz} problem, numpy restatement (oracle/mfs_oracle.py), fp64"
-    return {"value": cells * iters / dt / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
-            "sample": sample, "iters_per_s": iters / dt, "host_cpus": os.cpu_count()}
+    out = {"value": cells * iters / dt / 1e6, "unit": "Mcells/s", "cores": cores, "kind": "port",
+           "sample": sample, "iters_per_s": iters / dt, "host_cpus": os.cpu_count()}
+    if cores > 1 and not args.no_numpy_leg:
+        # SURVEY.md 8(d) asks for both CPU legs: the numpy restatement too (vectorised, effectively one core), 2 iterations
+        n_it = 2
+        x, d, r, q = (np.zeros(gres) for _ in range(4))
+        ap = lambda V, Q: O.pressure_apply3d(gres, V[0], Q[0], wx, wy, wz, sc["lphi"])  # noqa: E731
+        t0 = time.perf_counter()
+        O.cg(ap, b, x, d, r, q, 0.0, n_it, raise_on_fail=False)
+        dtn = time.perf_counter() - t0
+        out["numpy_port"] = {"value": cells * n_it / dtn / 1e6, "unit": "Mcells/s", "cores": 1, "iters_per_s": n_it / dtn,
+                             "sample": f"{n_it} CG iterations of the same problem, numpy restatement (oracle/mfs_oracle.py), fp64"}
+    return out
 
 
 def build_problem(torch, dev, tdt, lgres, ggrid, seed, x_range):
