@@ -144,6 +144,46 @@ def timestep_sharded_mode(rank, world, path, out, dtname, dev):
     sim.close()
 
 
+def timestep_synth_mode(rank, world, out, dev):
+    """a buckling-like synthetic scene (tools/bench_timestep.py's, at 32^3 with ~33 k particles moving at -2 in x, so
+    that particles cross the slab cuts every step): ShardedNotebookSimulation on `world` ranks; world == 1 with
+    P2P_TEST_SINGLE=1 runs the plain single-GPU NotebookSimulation as the reference of the comparison"""
+    import notebook_sim as NSIM
+    import solver.sdf3D as sdf
+    N, steps = 32, 4
+    gdx = 1.0 / N
+    bmin = [-0.5, 0.0, -0.5]
+    rb_d, rb_map = sdf.generate_rb(None, {}, 'cube', ['box', 1 - 4 * gdx, 1 - 4 * gdx, 1 - 4 * gdx], flip=True, center=[0, 0.5, 0], device=dev)
+    h = 0.35
+    for nm, par, c, ax, ang in (("p1", ['box', 0.67, 0.05, 1.2], [-0.42, h, 0], [0, 0, 1], -45), ("p2", ['box', 0.67, 0.05, 1.2], [0.42, h, 0], [0, 0, 1], 45)):
+        rb_d, rb_map = sdf.generate_rb(rb_d, rb_map, nm, par, flip=False, center=c, axis=ax, angle=ang)
+    px = NSIM.add_box([0.0, 0.7, 0.0], [0.5, 0.5, 0.5], gdx / 2, np.random.default_rng(0))
+    single = os.environ.get("P2P_TEST_SINGLE") == "1"
+    if single:
+        sim = NSIM.NotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=1.0, device=dev)
+        sim.particle.v[:, 0] = -2.0
+    else:
+        sim = NSIM.ShardedNotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=1.0, device=dev, dist=dist,
+                                             transport=os.environ.get("P2P_TEST_TRANSPORT", "auto"))
+        sim.particle.v[:, 0] = -2.0
+    res = {}
+    moved = 0
+    for s in range(steps):
+        before = None if single else sim.particle.id.clone()
+        res[f"dt{s + 1}"] = sim.step()
+        if single:
+            res[f"px{s + 1}"], res[f"pv{s + 1}"] = sim.particle.x.cpu().numpy(), sim.particle.v.cpu().numpy()
+        else:
+            ids, x, v, counts = sim.gather_particles()
+            assert ids.numpy().tolist() == list(range(sim.total_particles))
+            res[f"px{s + 1}"], res[f"pv{s + 1}"], res[f"counts{s + 1}"] = x.numpy(), v.numpy(), np.array(counts)
+            now = set(sim.particle.id.cpu().numpy().tolist())
+            moved += len(now - set(before.cpu().numpy().tolist()))
+    np.savez(f"{out}.rank{rank}.npz", steps=steps, arrivals=moved, **res)
+    if not single:
+        sim.close()
+
+
 def _close_after_fault(win):
     """teardown of the fault-injection modes: the group may be broken by the timed-out collective (gloo closes the
     pair), so the window's closing barrier is best-effort and the process leaves without a collective teardown."""
@@ -230,6 +270,12 @@ def main():
     if os.environ.get("P2P_TEST_MODE") == "density":
         try:
             density_mode(rank, world, path, out, dtname, dev)
+        finally:
+            dist.destroy_process_group()
+        return
+    if os.environ.get("P2P_TEST_MODE") == "timestep_synth":
+        try:
+            timestep_synth_mode(rank, world, out, dev)
         finally:
             dist.destroy_process_group()
         return
