@@ -235,10 +235,11 @@ __device__ __forceinline__ unsigned vm_mask(const unsigned char* p) {
 
 // store the computed cells of one component's vector (the z = 0 / z = Nz-1 cells of a row are array-boundary faces:
 // never written)
-template <typename T, int VEC, bool ALIGNED>
+template <typename T, int VEC, bool ALIGNED, int NT>
 __device__ __forceinline__ void vm_store(T* p, vec_t<T, VEC> o, bool first, bool last) {
   if (!first && !last) {
-    if (ALIGNED) vstore<T, VEC>(p, o); else vstore_u<T, VEC>(p, o);
+    if (ALIGNED) { if (NT & 4) vstore_nt<T, VEC>(p, o); else vstore<T, VEC>(p, o); }
+    else vstore_u<T, VEC>(p, o);
   } else {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -257,6 +258,14 @@ template <typename T, int VEC>
 __host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing * 3 * vm_su<VEC>(Nz) * sizeof(T); }
 
 #define MFS_VM_PIN() __builtin_amdgcn_sched_barrier(0)
+// nontemporal hints (template NT; the host turns them on when the launch's working set exceeds the Infinity Cache, as the
+// pressure engine does).  Bit 0: loads of the classes whose lines nobody reads twice in a launch (x-, y-, z-face classes,
+// xz-edge class: own vectors only, their z-neighbours come by DPP); bit 1: the own rows of C / EXY / EYZ as well (A/B only:
+// their y-neighbour rows are then re-fetched, 216 -> 241 us); bit 2: the q stores (read next by the r update, long after
+// they have left the caches at this size).  Same-box A/B at 256^3 fp32, us per launch: none 216.1, loads 216.2, stores
+// 209.1, loads + stores 204.1 (CG iteration 504 -> 487).
+#define MFS_VM_LD1(p) ((NT & 1) ? vload_nt<T, VEC>(p) : vload<T, VEC>(p))
+#define MFS_VM_LD2(p) ((NT & 2) ? vload_nt<T, VEC>(p) : vload<T, VEC>(p))
 // In-kernel stamps (diagnostic build only, -DMFS_VM_STAMPS; tools/vm_stamps.py): where a step's cycles go.  One stamp =
 // s_memtime + lgkmcnt(0) in one statement, fenced by scheduling barriers; the segment sums of the first 64 workgroups'
 // waves go to the upper half of the partial-sum array, which nothing else reads.
@@ -287,7 +296,7 @@ __host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing 
 #endif
 
 // slabs: the three boundary slabs (u at x = Nx-1, v at y = Ny-1, w at z = Nz-1) ride as extra blocks, as in k_vcg_apply_all
-template <typename T, int VEC, int WAVES>
+template <typename T, int VEC, int WAVES, int NT>
 __global__ void __launch_bounds__(kVmBlock, WAVES)
 k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
                   int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
@@ -427,7 +436,10 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       MFS_VISC_LDS_BARRIER();
       MFS_VM_STAMP(1);                                           // barrier
       // ---- (2) in flight for the whole step: own rows and halo vectors of plane x+2 (clamped at the end: unused)
-      const Plane pn = fetch(min(x + 2, Nx - 1));
+      // (the last two steps of a march need no further plane, its last step no further class samples: wave-uniform skips)
+      const bool need_plane = x + 2 <= x1, more = x + 1 < x1;
+      Plane pn = Plane{};
+      if (need_plane) pn = fetch(x + 2);
       const T* const qn = C1 + (int64_t)min(x + 1, Nx - 2) * sc + o_c;      // next step's class samples
       const unsigned char* const mqn = MP + (int64_t)min(x + 1, Nx - 2) * sc + o_c;
       MFS_VM_PIN();
@@ -447,11 +459,14 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       V qu;
       vm_row<T, VEC, 0>(rg, k1, k2, msk, qu, first, last, active, acc);
       MFS_VM_STAMP(4);                                           // u: rows (includes the wait for this step's class samples)
-      if (active) vm_store<T, VEC, true>(ox + (int64_t)x * su + o_uv, qu, first, last);
+      if (active) vm_store<T, VEC, true, NT>(ox + (int64_t)x * su + o_uv, qu, first, last);
       MFS_VM_PIN();
-      const V fxn = vload<T, VEC>(qn + 2 * cs), ccn = vload<T, VEC>(qn + 6 * cs), exyypn = vload<T, VEC>(qn + MFS_VM_NBR(c.pz));
+      V fxn = V{}, ccn = V{}, exyypn = V{};
       T exzzrn = (T)0;
-      if (fixr) exzzrn = qn[cs + VEC];
+      if (more) {
+        fxn = MFS_VM_LD1(qn + 2 * cs); ccn = MFS_VM_LD2(qn + 6 * cs); exyypn = vload<T, VEC>(qn + MFS_VM_NBR(c.pz));
+        if (fixr) exzzrn = qn[cs + VEC];
+      }
       MFS_VM_PIN();
       MFS_VM_STAMP(5);                                           // u: store + issue of the next step's samples
       // ---- (4) v rows
@@ -472,12 +487,16 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       V qv;
       vm_row<T, VEC, 1>(rg, k1, k2, msk, qv, first, last, active, acc);
       MFS_VM_STAMP(7);                                           // v: rows
-      if (active) vm_store<T, VEC, true>(oy + (int64_t)x * sv + o_uv, qv, first, last);
+      if (active) vm_store<T, VEC, true, NT>(oy + (int64_t)x * sv + o_uv, qv, first, last);
       MFS_VM_PIN();
-      const V fyn = vload<T, VEC>(qn + 4 * cs), cymn = vload<T, VEC>(qn + 6 * cs - MFS_VM_NBR(c.pz)), exypn = vload<T, VEC>(qn + sc);
+      V fyn = V{}, cymn = V{}, exypn = V{};
       T eyzzrn = (T)0;
-      if (fixr) eyzzrn = qn[3 * cs + VEC];
-      const unsigned mskn = MFS_VM_MK(vm_mask<VEC>(mqn));
+      unsigned mskn = 0;
+      if (more) {
+        fyn = MFS_VM_LD1(qn + 4 * cs); cymn = vload<T, VEC>(qn + 6 * cs - MFS_VM_NBR(c.pz)); exypn = MFS_VM_LD2(qn + sc);
+        if (fixr) eyzzrn = qn[3 * cs + VEC];
+        mskn = MFS_VM_MK(vm_mask<VEC>(mqn));
+      }
       MFS_VM_PIN();
       MFS_VM_STAMP(8);                                           // v: store + issue
       // ---- (5) w rows
@@ -498,15 +517,18 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       V qw;
       vm_row<T, VEC, 2>(rg, k1, k2, msk, qw, first, last, active, acc);
       MFS_VM_STAMP(10);                                          // w: rows
-      if (active) vm_store<T, VEC, false>(oz + (int64_t)x * sw + o_w, qw, first, last);
+      if (active) vm_store<T, VEC, false, NT>(oz + (int64_t)x * sw + o_w, qw, first, last);
       MFS_VM_PIN();
-      const V fzn = vload<T, VEC>(qn + 5 * cs), exzpn = vload<T, VEC>(qn + cs + sc), eyzcn = vload<T, VEC>(qn + 3 * cs),
-              eyzypn = vload<T, VEC>(qn + 3 * cs + MFS_VM_NBR(c.pz));
+      V fzn = V{}, exzpn = V{}, eyzcn = V{}, eyzypn = V{};
       T czln = (T)0;
-      if (fixl) czln = qn[6 * cs - 1];
+      if (more) {
+        fzn = MFS_VM_LD1(qn + 5 * cs); exzpn = MFS_VM_LD1(qn + cs + sc); eyzcn = MFS_VM_LD2(qn + 3 * cs);
+        eyzypn = vload<T, VEC>(qn + 3 * cs + MFS_VM_NBR(c.pz));
+        if (fixl) czln = qn[6 * cs - 1];
+      }
       MFS_VM_PIN();
       // ---- (6) plane x+2 into its slot (its loads have had the whole step); next step's class samples take over
-      publish(bw, pn);
+      if (need_plane) publish(bw, pn);
       MFS_VM_STAMP(11);                                          // w: store + issue, publish of plane x+2 (waits for its loads)
       rg.cm = rg.cc; rg.cc = ccn;
       rg.exyc = rg.exyp; rg.exyp = exypn; rg.exzc = rg.exzp; rg.exzp = exzpn;

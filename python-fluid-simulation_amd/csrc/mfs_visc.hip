@@ -758,9 +758,9 @@ static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
   return true;
 }
 
-template <typename T, int VEC, int WAVES>
-static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
-                            int* nparts) {
+template <typename T, int VEC, int WAVES, int NT>
+static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
+                               int* nparts) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + kVmBlock - 1) / kVmBlock;
   const int64_t total = (int64_t)tiles * (Nx - 2);
@@ -771,15 +771,26 @@ static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* par
   const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
   static bool attr_set = false;        // per instantiation: more than the default 64 KB of dynamic LDS
   if (!attr_set) {
-    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kVmMaxLds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
+  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
                      h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial, done);
   MFS_LAUNCH_CHECK();
   *nparts = gmain + g0 + g1 + g2;
   return MFS_OK;
+}
+
+template <typename T, int VEC, int WAVES>
+static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
+                            int* nparts) {
+  // nontemporal class loads / q stores once operand, result and classes (13 arrays) exceed the Infinity Cache
+  // (MFS_VISC_MARCH_NT = 0 / 1 overrides; read per launch so that an A/B can toggle it on one engine)
+  const int knob = env_int("MFS_VISC_MARCH_NT", -1);
+  const bool nt = knob < 0 ? (13.0 * (double)h->g.N[0] * h->g.N[1] * h->g.N[2] * sizeof(T) > 200e6) : (knob != 0);
+  return nt ? vcg_march_launch_nt<T, VEC, WAVES, 5>(h, vv, ob, partial, done, st, nparts)
+            : vcg_march_launch_nt<T, VEC, WAVES, 0>(h, vv, ob, partial, done, st, nparts);
 }
 
 template <typename T, bool MASK>
