@@ -698,6 +698,13 @@ static int64_t class_count(const int64_t gres[3], int /*p*/) {
   return (gres[0] + 1) * (gres[1] + 1) * (gres[2] + 4);
 }
 
+// byte distance between consecutive class arrays in the workspace.  The pad staggers the seven streams a workgroup reads at
+// the same in-plane offset (MFS_VISC_CLASS_PAD: A/B knob, a multiple of 256; read at every call, so keep it fixed in a process)
+static size_t class_stride_bytes(const int64_t gres[3], int dt) {
+  const size_t pad = (size_t)std::max(256, env_int("MFS_VISC_CLASS_PAD", 4096)) / 256 * 256;
+  return align_up((size_t)class_count(gres, 0) * dtype_size(dt), 4096) + pad;
+}
+
 static int check_gres(const int64_t gres[3]) {
   MFS_REQUIRE(gres != nullptr, "gres is null");
   for (int a = 0; a < 3; ++a) MFS_REQUIRE(gres[a] >= 1 && gres[a] <= 2048, "grid resolution out of range [1,2048]");
@@ -1151,7 +1158,7 @@ int mfs_visc_writeback3d(const int64_t gres[3], void* vx, void* vy, void* vz, in
 size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   size_t tot = core_ws_bytes() + 4096;
-  for (int p = 1; p < 8; ++p) tot += align_up((size_t)class_count(gres, p) * dtype_size(dt), 4096) + 4096;
+  for (int p = 1; p < 8; ++p) tot += class_stride_bytes(gres, dt);
   tot += align_up((size_t)class_count(gres, 0), 4096);       // the packed mask bytes
   return tot;
 }
@@ -1182,7 +1189,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->cp.py = h->g.N[1] + 1;
   h->cp.pz = h->g.N[2] + 4;
   h->cp.vol[0] = nullptr;
-  for (int q = 1; q < 8; ++q) { h->cp.vol[q] = p; p += align_up((size_t)class_count(gres, q) * h->c.elt, 4096) + 4096; }
+  for (int q = 1; q < 8; ++q) { h->cp.vol[q] = p; p += class_stride_bytes(gres, dt); }
   h->cp.msk = (unsigned char*)p; p += align_up((size_t)class_count(gres, 0), 4096);
   h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
   h->is_setup = false;

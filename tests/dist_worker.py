@@ -319,6 +319,56 @@ def run_lost_peer(rank, world, port, path, timeout_s):
     os._exit(0)                                 # no collective teardown with a peer that has given up
 
 
+def run_bands(rank, world, port, path, nx):
+    """SlabBands (the particle-sharded time step's plane-band exchanges and particle migration) over gloo on CPU tensors:
+    every rank fills a global-shaped field only from 'its own particles', reduces, fetches ghosts, migrates; the results
+    are checked against the single-process answer by the test."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from mfs.dist import SlabBands, pg_timeout
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout())
+    try:
+        B = SlabBands(dist, None, nx)
+        rng = np.random.default_rng(5)
+        P = 4000
+        cell = rng.integers(0, nx, size=P)                        # every rank draws the SAME particle set
+        wgt = rng.standard_normal(P)
+        ids = np.arange(P)
+        mine = np.asarray(B.owner_of_cells(torch.as_tensor(cell)).numpy() == rank)
+        out = {}
+        for kind, n, scale in (("cell", nx, 1), ("xface", nx + 1, 1), ("doubled", 2 * nx + 1, 2)):
+            for op in ("sum", "min"):
+                f = torch.zeros((n, 3, 2), dtype=torch.float64) if op == "sum" else torch.full((n, 3, 2), 9.0, dtype=torch.float64)
+                for c, w in zip(cell[mine], wgt[mine]):          # a scatter with reach 2 cells in x
+                    for dxx in range(-2 * scale, 2 * scale + 1):
+                        pl = min(max(c * scale + dxx, 0), n - 1)
+                        if op == "sum":
+                            f[pl] += w
+                        else:
+                            f[pl] = torch.minimum(f[pl], torch.full((3, 2), float(w), dtype=torch.float64))
+                B.reduce([f], kind, 3, op)
+                a, b = B.owned(kind)
+                owned = f[a:b].clone()
+                f2 = f.clone()
+                f2[:a] = -777.0                                    # whatever sits outside the range must be replaced by ghosts
+                f2[b:] = -777.0
+                B.ghosts([f2], kind, 4)
+                out[f"{kind}_{op}_owned"] = owned.numpy()
+                out[f"{kind}_{op}_ghosted"] = f2.numpy()
+                out[f"{kind}_own"] = np.array([a, b])
+        # migration: every particle moves to a random new cell; fields travel with it
+        newcell = np.random.default_rng(6).integers(0, nx, size=P)
+        fields = [torch.as_tensor(wgt[mine]), torch.as_tensor(np.stack([wgt[mine], 2 * wgt[mine], 3 * wgt[mine]], 1)),
+                  torch.as_tensor(ids[mine])]
+        dest = B.owner_of_cells(torch.as_tensor(newcell[mine]))
+        w2, v2, id2 = B.migrate(fields, dest)
+        out["mig_ids"], out["mig_w"], out["mig_v"] = id2.numpy(), w2.numpy(), v2.numpy()
+        out["mig_expected_owner"] = B.owner_of_cells(torch.as_tensor(newcell)).numpy()
+        np.savez(f"{path}.rank{rank}.npz", cell=cell, wgt=wgt, bytes_moved=B.bytes_moved, **out)
+    finally:
+        dist.destroy_process_group()
+
+
 def run(rank, world, port, path, tol, overlap, max_iter):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -151,3 +151,44 @@ def test_collective_loop_reports_a_lost_peer():
         secs, outcome = open(path + ".rank0.txt").read().strip().split("\n")
     assert outcome.startswith("MfsTimeout") and "status -4" in outcome and "timed out" in outcome, outcome
     assert float(secs) < 15.0, secs
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_slab_bands_reduce_ghosts_migrate(world):
+    """mfs.dist.SlabBands over gloo: band reduce (sum / min), ghost fetch and particle migration for the three array kinds
+    ("cell", "xface", "doubled"), thin slabs included (world 4 on 12 planes: bands span two neighbours) -- against the
+    single-process scatter of all particles."""
+    nx = 12
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "bands")
+        mp.spawn(dist_worker.run_bands, args=(world, _free_port(), path, nx), nprocs=world, join=True)
+        outs = [dict(np.load(f"{path}.rank{r}.npz")) for r in range(world)]
+    cell, wgt = outs[0]["cell"], outs[0]["wgt"]
+    for kind, n, scale in (("cell", nx, 1), ("xface", nx + 1, 1), ("doubled", 2 * nx + 1, 2)):
+        for op in ("sum", "min"):
+            full = np.zeros((n, 3, 2)) if op == "sum" else np.full((n, 3, 2), 9.0)
+            for c, w in zip(cell, wgt):
+                for dxx in range(-2 * scale, 2 * scale + 1):
+                    pl = min(max(c * scale + dxx, 0), n - 1)
+                    if op == "sum":
+                        full[pl] += w
+                    else:
+                        full[pl] = np.minimum(full[pl], w)
+            covered = np.zeros(n, bool)
+            for o in outs:
+                a, b = o[f"{kind}_own"]
+                assert not covered[a:b].any()
+                covered[a:b] = True
+                np.testing.assert_allclose(o[f"{kind}_{op}_owned"], full[a:b], rtol=1e-12, atol=1e-12)
+                w_ = 4 * scale
+                lo, hi = max(0, a - w_), min(n, b + w_)
+                np.testing.assert_allclose(o[f"{kind}_{op}_ghosted"][lo:hi], full[lo:hi], rtol=1e-12, atol=1e-12)
+            assert covered.all()
+    # migration: every particle ends on the rank that owns its new cell, with its fields, exactly once
+    seen = np.concatenate([o["mig_ids"] for o in outs])
+    assert sorted(seen.tolist()) == list(range(len(cell)))
+    for r, o in enumerate(outs):
+        assert (o["mig_expected_owner"][o["mig_ids"]] == r).all()
+        np.testing.assert_array_equal(o["mig_w"], wgt[o["mig_ids"]])
+        np.testing.assert_array_equal(o["mig_v"][:, 2], 3 * wgt[o["mig_ids"]])
+        assert int(o["bytes_moved"]) > 0
