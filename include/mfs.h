@@ -128,6 +128,11 @@ int mfs_pcg3d_finish(mfs_pcg3d* h, mfs_stream stream);
  * the end of mfs_pcg3d_solve.  on < 0 = auto (default; env MFS_DEFER_X): only when the CG vectors exceed the
  * Infinity Cache.  A caller of mfs_pcg3d_iterate must therefore end with mfs_pcg3d_finish before reading x.   */
 int mfs_pcg3d_set_defer_x(mfs_pcg3d* h, int on);
+/* native fused loop without the deferred x update: mfs_pcg3d_iterate closes iteration j (convergence test :218, beta :220,
+ * history) at the top of the stencil launch of iteration j + 1 -- every workgroup folds the r.r partials itself -- and
+ * ends a batch with a one-block bookkeeping launch, instead of a reduction tail in the x/r update.  Same values, bit
+ * for bit; shorter dependent chain per iteration (what bounds small grids).  on < 0 = auto (default; env MFS_LEAN). */
+int mfs_pcg3d_set_lean(mfs_pcg3d* h, int on);
 /* synchronises `stream`, then reports the device-resident solver state. host call. */
 int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);

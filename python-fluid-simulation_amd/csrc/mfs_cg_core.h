@@ -218,33 +218,56 @@ __global__ void __launch_bounds__(kBlock)
 k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
             double* __restrict__ scal, double* __restrict__ partial, int rev, int par,
             const double* __restrict__ part_dq, int npart, XrTail tail, P2pDev pd) {
-  if (scal[S_DONE] != 0.0) return;
+  // Everything this block needs first is requested in ONE batch -- the done flag, the delta ring, the d.q partials and
+  // the first vector of every lane -- and only then waited for: on a small grid the kernel is a chain of memory round
+  // trips, and flag -> partials -> vectors in sequence were three of them.  (Loads past a raised flag are harmless.)
+  const double dn = scal[S_DONE];
+  const double delta = scal[S_RING + par];
+  const int64_t nv = n / VEC;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t k0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool rv_ = rev != 0;
+  vec_t<T, VEC> xv = {}, dv = {}, rv = {}, qv = {};
+  auto fetch = [&](int64_t i) {
+    if (MODE != 1) {
+      xv = NTX ? vload_nt<T, VEC>(x + i) : vload<T, VEC>(x + i);
+      dv = vload<T, VEC>(d + i);
+    }
+    if (MODE != 2) {
+      rv = vload<T, VEC>(r + i);     // (streaming r here as well: no gain for viscosity, -1 % for pressure)
+      // MODE 1 with NTX (x is not touched here): q -- written by the apply, read only here -- is streamed instead
+      qv = (MODE == 1 && NTX) ? vload_nt<T, VEC>(q + i) : vload<T, VEC>(q + i);
+    }
+  };
+  if (k0 < nv) fetch((rv_ ? nv - 1 - k0 : k0) * VEC);
   // d.q: folded reduction of the apply's partials (npart > 0) or the all-reduced scalar
   const double dq = npart > 0 ? block_total_of(part_dq, npart) : scal[S_DQ];
+  if (dn != 0.0) return;
   if (npart > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;   // kept for the history entry
-  const double alpha = scal[S_RING + par] / dq;
+  const double alpha = delta / dq;
   double acc = 0.0;
-  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
-    if (vec) {
-      if (MODE != 1) {
-        vec_t<T, VEC> xv = NTX ? vload_nt<T, VEC>(x + i) : vload<T, VEC>(x + i);
-        const vec_t<T, VEC> dv = vload<T, VEC>(d + i);
+  // sweep direction: see for_each_vec (same order of the vectors per lane, so the r.r partials group identically)
+  for (int64_t k = k0; k < nv; k += stride) {
+    const int64_t i = (rv_ ? nv - 1 - k : k) * VEC;
+    if (k != k0) fetch(i);
+    if (MODE != 1) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
-        if (NTX) vstore_nt<T, VEC>(x + i, xv); else vstore<T, VEC>(x + i, xv);
-      }
-      if (MODE != 2) {
-        vec_t<T, VEC> rv = vload<T, VEC>(r + i);     // (streaming r here as well: no gain for viscosity, -1 % for pressure)
-        // MODE 1 with NTX (x is not touched here): q -- written by the apply, read only here -- is streamed instead
-        const vec_t<T, VEC> qv = (MODE == 1 && NTX) ? vload_nt<T, VEC>(q + i) : vload<T, VEC>(q + i);
+      for (int j = 0; j < VEC; ++j) xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
+      if (NTX) vstore_nt<T, VEC>(x + i, xv); else vstore<T, VEC>(x + i, xv);
+    }
+    if (MODE != 2) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
-          acc += (double)rv[j] * (double)rv[j];
-        }
-        vstore<T, VEC>(r + i, rv);
+      for (int j = 0; j < VEC; ++j) {
+        rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
+        acc += (double)rv[j] * (double)rv[j];
       }
-    } else {
+      vstore<T, VEC>(r + i, rv);
+    }
+  }
+  {   // scalar tail (n % VEC elements): the first threads of block 0, after their vectors
+    const int64_t rest = n - nv * VEC;
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < rest) {
+      const int64_t i = nv * VEC + threadIdx.x;
       if (MODE != 1) x[i] = (T)((double)x[i] + alpha * (double)d[i]);
       if (MODE != 2) {
         const T rn = (T)((double)r[i] - alpha * (double)q[i]);
@@ -252,7 +275,7 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
         acc += (double)rn * (double)rn;
       }
     }
-  }, rev != 0);
+  }
   if (MODE != 2) {
     const double tot = block_sum<kBlock>(acc);
     if (tail.kind == 0) {

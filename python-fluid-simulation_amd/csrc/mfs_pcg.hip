@@ -199,6 +199,7 @@ struct mfs_pcg3d {
   void* d2;                    // ping-pong partner of the bound d (fused direction update)
   int pd;                      // prefetch depth (planes) of the operand stream in the LDS march: 1 or 2
   int fuse;                    // 1: native loop folds d = r + beta d into the stencil launch
+  int lean;                    // mfs_pcg3d_iterate closes iteration j in the stencil launch of j + 1 (no reduction tail in the update): 1 / 0 / -1 auto
   unsigned char* cls;          // class byte per z-vector (compressed coefficient access)
   int compress;                // 1: per-iteration kernel skips the coefficient arrays of ZERO / REGULAR vectors
   int grid_apply, cus;
@@ -217,7 +218,8 @@ struct mfs_pcg3d {
 // streams of one tile do not all start on the same HBM channel/bank phase.
 static size_t coef_stride(int64_t n, size_t elt) { return align_up((size_t)n * elt, 4096) + 4096 * 3 + 256; }
 
-struct FuseArgs { const void* r; const void* d_old; void* d_new; void* xdef = nullptr; };   // xdef: deferred x update rides along
+// xdef: deferred x update rides along.  book: the launch also closes the previous iteration (BookArgs in mfs_pcg_apply.h)
+struct FuseArgs { const void* r; const void* d_old; void* d_new; void* xdef = nullptr; bool book = false; };
 
 template <typename T, int VEC>
 static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int xb2, int xe2, double* partial,
@@ -265,6 +267,23 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
       MFS_REQUIRE(fz == nullptr, "the fused direction update needs the LDS march");
       if (asym) { if (nt) MFS_GO(false, 1, false, false, 1, true); else MFS_GO(false, 0, false, false, 1, true); }
       else      { if (nt) MFS_GO(false, 1, false, false, 1, false); else MFS_GO(false, 0, false, false, 1, false); }
+    } else if (fz && fz->book) {
+      // fused direction update + the bookkeeping of the previous iteration (PD 1, no deferred x)
+      MFS_REQUIRE(!fz->xdef, "the closing stencil launch does not carry the deferred x update");
+      const BookArgs bk{h->c.scal, h->c.hist, kHistCap, h->c.part_rr, h->c.n_part_rr, (int)((h->c.iter_enq - 1) & 1)};
+#define MFS_GO_B(NTV, CMP, ASY)                                                                                        \
+      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, false, true>), dim3(grid),           \
+                         dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done,                 \
+                         (const T*)fz->r, (const T*)fz->d_old, (T*)fz->d_new, (const double*)nullptr, cz2,             \
+                         (T*)nullptr, (const double*)nullptr, bk)
+      if (asym) {
+        if (comp) { if (nt) MFS_GO_B(7, true, true); else MFS_GO_B(0, true, true); }
+        else      { if (nt) MFS_GO_B(7, false, true); else MFS_GO_B(0, false, true); }
+      } else {
+        if (comp) { if (nt) MFS_GO_B(7, true, false); else MFS_GO_B(0, true, false); }
+        else      { if (nt) MFS_GO_B(7, false, false); else MFS_GO_B(0, false, false); }
+      }
+#undef MFS_GO_B
     } else if (asym) {
       if (fz) MFS_GO_NT_CMP(true, 1, true); else MFS_GO_NT_CMP(false, 1, true);
     } else if (fz && fz->xdef) {
@@ -357,6 +376,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->jacobi = env_int("MFS_JACOBI", 0);
   h->defer_x = env_int("MFS_DEFER_X", -1);
   h->x_owed = false;
+  h->lean = env_int("MFS_LEAN", -1);
   h->slab_loop = false;
   h->fuse = env_int("MFS_FUSE_D", 1);
   h->pd = env_int("MFS_APPLY_PD", 1);
@@ -481,6 +501,12 @@ int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on) {
 int mfs_pcg3d_set_defer_x(mfs_pcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
   h->defer_x = on < 0 ? -1 : (on != 0);
+  return MFS_OK;
+}
+
+int mfs_pcg3d_set_lean(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->lean = on < 0 ? -1 : (on != 0);
   return MFS_OK;
 }
 
@@ -673,8 +699,42 @@ int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
   return core_update_xr_close(h->c, true, st, (j & 1) ? h->d2 : h->c.d, 1);
 }
 
+// the tail-less form of the fused loop (see BookArgs): whenever the deferred x update is not in use
+static bool lean_ok(const mfs_pcg3d* h) {
+  return h->lean != 0 && native_fuse_ok(h) && !xdef_ok(h) && h->pd < 2;
+}
+
+// n iterations as  A_0 U | A*_1 U | ... | A*_{n-1} U | B : A plain fused stencil launch (beta from the scalar block),
+// A* = stencil launch that first closes the iteration before it, U = x/r update without a tail, B = one-block
+// bookkeeping for the last iteration of the batch -- so that the scalar block is complete whenever the host looks.
+static int pcg_iterate_lean(mfs_pcg3d* h, int64_t n, hipStream_t st) {
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t j = h->c.iter_enq;
+    void* d_cur = (j & 1) ? h->d2 : h->c.d;
+    void* d_prev = (j & 1) ? h->c.d : h->d2;
+    int grid = 0, e;
+    if (j == 0) {
+      if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid))) return e;
+    } else {
+      FuseArgs fz{h->c.r, d_prev, d_cur};
+      fz.book = i > 0;
+      if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e;
+    }
+    h->c.n_part_dq = grid;
+    if ((e = core_update_xr(h->c, true, st, 0, d_cur))) return e;
+    ++h->c.iter_enq;
+  }
+  if (n > 0) {
+    hipLaunchKernelGGL(k_cg_book, dim3(1), dim3(kBlock), 0, st, h->c.scal, h->c.hist, kHistCap,
+                       (int)((h->c.iter_enq - 1) & 1), h->c.part_rr, h->c.n_part_rr);
+    MFS_LAUNCH_CHECK();
+  }
+  return MFS_OK;
+}
+
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  if (!h->jacobi && lean_ok(h)) return pcg_iterate_lean(h, n, (hipStream_t)stream);
   if (h->jacobi) {
     const bool vec = core_vec_ok(h->c) && ((uintptr_t)h->diag % 16 == 0);
     for (int64_t i = 0; i < n; ++i) {

@@ -30,6 +30,7 @@
 //    block); no atomics, bitwise reproducible.
 #pragma once
 #include "mfs_common.h"
+#include "mfs_cg_core.h"
 
 // workgroup barrier that waits on LDS traffic only: global prefetches stay in flight across it
 #define MFS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -277,19 +278,47 @@ struct VSrc {
 // XDEF (with FUSE): the PREVIOUS iteration's solution update x += alpha d_old rides in this launch too -- each
 // vector is updated by the step that owns it, d_old re-read from cache -- so that the x/r update kernel only
 // touches r and q.  The march is latency-paced, extra streams are nearly free for it; same values as k_update_xr's.
-template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD, bool ASYM = false, bool XDEF = false>
+// BOOK (with FUSE, small grids): the launch also CLOSES the previous iteration -- every workgroup folds the r.r partials
+// of the preceding x/r update itself (block_total_of: same order, same value in every workgroup), takes the convergence
+// decision and beta from that, and workgroup 0 writes the bookkeeping (cg_book).  The update kernel then needs no
+// in-launch reduction tail (store -> ticket -> ticket -> acquire -> partials -> scalars: four dependent round trips that are
+// most of a 184 k-cell iteration).  The workgroups agree by construction: the decision is a function of values that
+// were complete before the launch.
+struct BookArgs {
+  double* scal;
+  double* hist;
+  int64_t hist_cap;
+  const double* part_rr;
+  int npart, par;
+};
+
+template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD, bool ASYM = false, bool XDEF = false,
+          bool BOOK = false>
 __global__ void __launch_bounds__(kApplyBlock, MFS_MARCH_MIN_WAVES)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
                   const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
                   const unsigned char* __restrict__ cls, ApplyArgs a, double* __restrict__ partial,
                   const double* __restrict__ done_flag, const T* __restrict__ fr, const T* __restrict__ fd_old,
                   T* __restrict__ fd_new, const double* __restrict__ beta_ptr, const T* __restrict__ cz2,
-                  T* __restrict__ xdef = nullptr, const double* __restrict__ alpha_ptr = nullptr) {
+                  T* __restrict__ xdef = nullptr, const double* __restrict__ alpha_ptr = nullptr, BookArgs bk = BookArgs{}) {
   static_assert(!XDEF || FUSE, "the deferred x update rides on the fused direction update");
+  static_assert(!BOOK || (FUSE && !XDEF), "closing the previous iteration rides on the plain fused direction update");
+  static_assert(kApplyBlock == kBlock, "block_total_of is written for kBlock threads");
   const double alpha_x = XDEF ? *alpha_ptr : 0.0;
   static_assert(!FUSE || LDS, "the fused direction update is implemented on the LDS march");
-  if (done_flag && *done_flag != 0.0) return;
-  const VSrc<T, VEC, FUSE> src{v, fr, fd_old, FUSE ? *beta_ptr : 0.0};
+  // BOOK: the flag, the scalars and this lane's share of the r.r partials are REQUESTED here and consumed after the first
+  // march's own loads have been issued (book_pending below): one memory round trip instead of three in sequence.
+  double bk_dn = 0.0, bk_delta = 0.0, bk_dq = 0.0, bk_tol2 = 0.0, bk_acc = 0.0;
+  bool book_pending = BOOK;
+  double beta_v = 0.0;
+  if (BOOK) {
+    bk_dn = bk.scal[S_DONE]; bk_delta = bk.scal[S_RING + bk.par]; bk_dq = bk.scal[S_DQ]; bk_tol2 = bk.scal[S_TOL2];
+    for (int i = threadIdx.x; i < bk.npart; i += kBlock) bk_acc += bk.part_rr[i];      // block_total_of's order
+  } else {
+    if (done_flag && *done_flag != 0.0) return;
+    if (FUSE) beta_v = *beta_ptr;
+  }
+  VSrc<T, VEC, FUSE> src{v, fr, fd_old, beta_v};
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* const smem = reinterpret_cast<T*>(smem_raw);
   const int Nz = a.Nz;
@@ -337,13 +366,28 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     const int tile_len = min(tile_elems, ipp * VEC - tile * tile_elems);  // elements really in this tile
 
     int64_t base = (int64_t)x0 * sx + m;
-    vec_t<T, VEC> vm = src.ld(base - sx), vc = src.ld(base), vp = src.ld(base + sx);
+    const RawVec<T, VEC> wm = src.raw(base - sx), wc = src.raw(base), wp = src.raw(base + sx);
     // classes of this vector in planes x0 and x0+1 (compressed mode), then plane x0's coefficients
     unsigned char cls_n = kClsMixed, cls_c = kClsMixed;
     if (COMP) {
       cls_c = cls[base / VEC];
       cls_n = cls[(base + (x0 + 1 < x1 ? sx : 0)) / VEC];
     }
+    if (BOOK && book_pending) {                      // uniform over the workgroup: its first march
+      book_pending = false;
+      __shared__ double s_rr;
+      const double t = block_sum<kBlock>(bk_acc);
+      if (threadIdx.x == 0) s_rr = t;
+      __syncthreads();
+      const double rr = s_rr;                        // == block_total_of(bk.part_rr, bk.npart)
+      // the flag may have been raised by an EARLIER launch, or by workgroup 0 of this one for the very decision every
+      // workgroup takes here: same outcome
+      const bool stop = bk_dn != 0.0 || cg_health(bk_dq, rr) != 0 || rr < bk_tol2;
+      if (bk_dn == 0.0 && blockIdx.x == 0 && threadIdx.x == 0) cg_book(bk.scal, bk.hist, bk.hist_cap, bk.par, bk_dq, rr);
+      if (stop) return;
+      src.beta = rr / bk_delta;                      // cg_book's expression: the value it leaves in S_BETA
+    }
+    vec_t<T, VEC> vm = src.fin(wm), vc = src.fin(wc), vp = src.fin(wp);
     CoefVec<T, VEC> cc = coef_load<T, VEC, COMP, NT, true, ASYM>(diag, cx, cy, cz, base, sx, Nz, cls_c, cz2);
     if (!COMP) cc.cxm = vload<T, VEC>(cx + base);
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mfs_pcg3d_loop_info": (_i, [_p]),
     "mfs_pcg3d_set_jacobi": (_i, [_p, _i]),
     "mfs_pcg3d_set_defer_x": (_i, [_p, _i]),
+    "mfs_pcg3d_set_lean": (_i, [_p, _i]),
     "mfs_pcg3d_finish": (_i, [_p, _p]),
     "mfs_pcg3d_set_compress": (_i, [_p, _i]),
     "mfs_pcg3d_set_fuse": (_i, [_p, _i]),

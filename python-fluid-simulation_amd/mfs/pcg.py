@@ -56,6 +56,10 @@ class PcgEngine:
         b = int(self.lib.mfs_pcg3d_loop_info(self.h))
         return dict(fused_direction_update=bool(b & 1), deferred_x_update=bool(b & 2), jacobi=bool(b & 4))
 
+    def set_lean(self, on):
+        """close each iteration at the top of the next stencil launch instead of in a reduction tail (None = auto)"""
+        _lib.check(self.lib.mfs_pcg3d_set_lean(self.h, -1 if on is None else int(bool(on))), "mfs_pcg3d_set_lean")
+
     def set_defer_x(self, on):
         _lib.check(self.lib.mfs_pcg3d_set_defer_x(self.h, -1 if on is None else int(bool(on))), "mfs_pcg3d_set_defer_x")
 
