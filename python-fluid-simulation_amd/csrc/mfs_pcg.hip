@@ -268,20 +268,23 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
       if (asym) { if (nt) MFS_GO(false, 1, false, false, 1, true); else MFS_GO(false, 0, false, false, 1, true); }
       else      { if (nt) MFS_GO(false, 1, false, false, 1, false); else MFS_GO(false, 0, false, false, 1, false); }
     } else if (fz && fz->book) {
-      // fused direction update + the bookkeeping of the previous iteration (PD 1, no deferred x)
-      MFS_REQUIRE(!fz->xdef, "the closing stencil launch does not carry the deferred x update");
+      // fused direction update + the bookkeeping of the previous iteration (PD 1), with or without the deferred x update
       const BookArgs bk{h->c.scal, h->c.hist, kHistCap, h->c.part_rr, h->c.n_part_rr, (int)((h->c.iter_enq - 1) & 1)};
-#define MFS_GO_B(NTV, CMP, ASY)                                                                                        \
-      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, false, true>), dim3(grid),           \
+#define MFS_GO_B(NTV, CMP, ASY, XDF)                                                                                   \
+      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, XDF, true>), dim3(grid),             \
                          dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done,                 \
                          (const T*)fz->r, (const T*)fz->d_old, (T*)fz->d_new, (const double*)nullptr, cz2,             \
-                         (T*)nullptr, (const double*)nullptr, bk)
-      if (asym) {
-        if (comp) { if (nt) MFS_GO_B(7, true, true); else MFS_GO_B(0, true, true); }
-        else      { if (nt) MFS_GO_B(7, false, true); else MFS_GO_B(0, false, true); }
+                         (T*)fz->xdef, (const double*)nullptr, bk)
+      if (fz->xdef) {
+        MFS_REQUIRE(!asym, "the deferred x update is for the symmetric operator");
+        if (comp) { if (nt) MFS_GO_B(7, true, false, true); else MFS_GO_B(0, true, false, true); }
+        else      { if (nt) MFS_GO_B(7, false, false, true); else MFS_GO_B(0, false, false, true); }
+      } else if (asym) {
+        if (comp) { if (nt) MFS_GO_B(7, true, true, false); else MFS_GO_B(0, true, true, false); }
+        else      { if (nt) MFS_GO_B(7, false, true, false); else MFS_GO_B(0, false, true, false); }
       } else {
-        if (comp) { if (nt) MFS_GO_B(7, true, false); else MFS_GO_B(0, true, false); }
-        else      { if (nt) MFS_GO_B(7, false, false); else MFS_GO_B(0, false, false); }
+        if (comp) { if (nt) MFS_GO_B(7, true, false, false); else MFS_GO_B(0, true, false, false); }
+        else      { if (nt) MFS_GO_B(7, false, false, false); else MFS_GO_B(0, false, false, false); }
       }
 #undef MFS_GO_B
     } else if (asym) {
@@ -699,15 +702,16 @@ int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
   return core_update_xr_close(h->c, true, st, (j & 1) ? h->d2 : h->c.d, 1);
 }
 
-// the tail-less form of the fused loop (see BookArgs): whenever the deferred x update is not in use
+// the tail-less form of the fused loop (see BookArgs)
 static bool lean_ok(const mfs_pcg3d* h) {
-  return h->lean != 0 && native_fuse_ok(h) && !xdef_ok(h) && h->pd < 2;
+  return h->lean != 0 && native_fuse_ok(h) && h->pd < 2;
 }
 
 // n iterations as  A_0 U | A*_1 U | ... | A*_{n-1} U | B : A plain fused stencil launch (beta from the scalar block),
 // A* = stencil launch that first closes the iteration before it, U = x/r update without a tail, B = one-block
 // bookkeeping for the last iteration of the batch -- so that the scalar block is complete whenever the host looks.
 static int pcg_iterate_lean(mfs_pcg3d* h, int64_t n, hipStream_t st) {
+  const bool xdef = xdef_ok(h);
   for (int64_t i = 0; i < n; ++i) {
     const int64_t j = h->c.iter_enq;
     void* d_cur = (j & 1) ? h->d2 : h->c.d;
@@ -718,10 +722,12 @@ static int pcg_iterate_lean(mfs_pcg3d* h, int64_t n, hipStream_t st) {
     } else {
       FuseArgs fz{h->c.r, d_prev, d_cur};
       fz.book = i > 0;
+      if (xdef) fz.xdef = h->c.x;
       if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e;
     }
     h->c.n_part_dq = grid;
-    if ((e = core_update_xr(h->c, true, st, 0, d_cur))) return e;
+    if (xdef) h->x_owed = true;                  // r only: x += alpha d rides in the next stencil launch
+    if ((e = core_update_xr(h->c, true, st, xdef ? 1 : 0, d_cur))) return e;
     ++h->c.iter_enq;
   }
   if (n > 0) {

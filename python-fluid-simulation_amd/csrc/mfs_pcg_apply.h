@@ -302,9 +302,9 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
                   T* __restrict__ fd_new, const double* __restrict__ beta_ptr, const T* __restrict__ cz2,
                   T* __restrict__ xdef = nullptr, const double* __restrict__ alpha_ptr = nullptr, BookArgs bk = BookArgs{}) {
   static_assert(!XDEF || FUSE, "the deferred x update rides on the fused direction update");
-  static_assert(!BOOK || (FUSE && !XDEF), "closing the previous iteration rides on the plain fused direction update");
+  static_assert(!BOOK || FUSE, "closing the previous iteration rides on the fused direction update");
   static_assert(kApplyBlock == kBlock, "block_total_of is written for kBlock threads");
-  const double alpha_x = XDEF ? *alpha_ptr : 0.0;
+  double alpha_x = (XDEF && !BOOK) ? *alpha_ptr : 0.0;
   static_assert(!FUSE || LDS, "the fused direction update is implemented on the LDS march");
   // BOOK: the flag, the scalars and this lane's share of the r.r partials are REQUESTED here and consumed after the first
   // march's own loads have been issued (book_pending below): one memory round trip instead of three in sequence.
@@ -385,7 +385,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const bool stop = bk_dn != 0.0 || cg_health(bk_dq, rr) != 0 || rr < bk_tol2;
       if (bk_dn == 0.0 && blockIdx.x == 0 && threadIdx.x == 0) cg_book(bk.scal, bk.hist, bk.hist_cap, bk.par, bk_dq, rr);
       if (stop) return;
-      src.beta = rr / bk_delta;                      // cg_book's expression: the value it leaves in S_BETA
+      src.beta = rr / bk_delta;                      // cg_book's expressions: the values it leaves in S_BETA
+      if (XDEF) alpha_x = bk_delta / bk_dq;          // and S_ALPHA (the step of the iteration being closed)
     }
     vec_t<T, VEC> vm = src.fin(wm), vc = src.fin(wc), vp = src.fin(wp);
     CoefVec<T, VEC> cc = coef_load<T, VEC, COMP, NT, true, ASYM>(diag, cx, cy, cz, base, sx, Nz, cls_c, cz2);

@@ -32,16 +32,16 @@ def test_optimised_loop_equals_plain_loop(gres, prec):
     seed = sum(gres)
     sc = scenes.pressure_scene_3d(gres, seed=seed, vel_dtype=np.float32, solid_velocity=bool(seed & 1))
     res = []
-    for mode in ("optimised", "plain", "deferred_x", "tailed"):
+    for mode in ("optimised", "plain", "deferred_x", "tailed", "deferred_x_tailed"):
         buf = B.CGSolverBuffer(gres, precision=prec, device=DEV)
         s = P.PressureCGSolver3D(buf, gres, sc["bound_size"], check_every=3)
         s.max_iter = 12                                  # a dozen iterations exercise every pipeline stage
         e = s._engine
         if mode == "plain":
             e.set_compress(False); e.set_fuse(False); e.set_prefetch(1)
-        if mode == "tailed":                             # the x/r update's last workgroup closes the iteration (the form
+        if mode.endswith("tailed"):                             # the x/r update's last workgroup closes the iteration (the form
             e.set_lean(False)                            # the default loop uses only with the deferred x update)
-        if mode == "deferred_x":                         # x += alpha d rides in the NEXT stencil launch (default only
+        if mode.startswith("deferred_x"):                         # x += alpha d rides in the NEXT stencil launch (default only
             e.set_defer_x(True)                          # beyond the Infinity Cache; forced here), flushed at the end
         v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
         try:
