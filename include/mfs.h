@@ -133,6 +133,12 @@ int mfs_pcg3d_set_defer_x(mfs_pcg3d* h, int on);
  * ends a batch with a one-block bookkeeping launch, instead of a reduction tail in the x/r update.  Same values, bit
  * for bit; shorter dependent chain per iteration (what bounds small grids).  on < 0 = auto (default; env MFS_LEAN). */
 int mfs_pcg3d_set_lean(mfs_pcg3d* h, int on);
+/* small grids (the reference notebook's 48x80x48 and the like): mfs_pcg3d_iterate runs a whole batch of iterations
+ * (PressureCGSolver3D.py:207-221) as ONE launch of <= 64 resident workgroups that keep x, r, d, q in registers and
+ * exchange the two dot products and the box faces through self-validating records in the workspace -- no kernel
+ * boundary per reduction.  Same arithmetic per cell; the grouping of the dot products differs from the launch-per-phase
+ * loops, so results agree with them to rounding.  on < 0 = auto (default; env MFS_RESIDENT): whenever the grid fits. */
+int mfs_pcg3d_set_resident(mfs_pcg3d* h, int on);
 /* synchronises `stream`, then reports the device-resident solver state. host call. */
 int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);
@@ -187,7 +193,7 @@ int mfs_pcg3d_tune(mfs_pcg3d* h, int variant, int xchunk, int blocks_per_cu, int
  * interior rows (class byte per vector built by mfs_pcg3d_setup); results are bit-identical */
 int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
 /* form of the native loop for the engine as bound: bit 0 = direction update fused into the stencil launch,
- * bit 1 = x update deferred into it too, bit 2 = Jacobi loop */
+ * bit 1 = x update deferred into it too, bit 2 = Jacobi loop, bit 3 = resident small-grid loop (mfs_pcg3d_set_resident) */
 int mfs_pcg3d_loop_info(mfs_pcg3d* h);
 /* OPT-IN Jacobi preconditioning of the native loop (default off; env MFS_JACOBI=1): z = r / diag fused into the
  * two vector phases, delta = r.z, convergence test unchanged (r.r < tol^2).  NOT the reference's algorithm -- the

@@ -50,10 +50,31 @@ __device__ __forceinline__ void stx(void* p, int dt, int64_t i, double v) {
 // ------------------------------------------------------------ reductions ----
 constexpr int kWave = 64;
 
+// one DPP data move of a double (two 32-bit moves); CTRL: quad_perm 0x00-0xff, row_ror:n 0x120 + n
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long d = __builtin_bit_cast(long long, v);
+  const int lo = (int)d, hi = (int)(d >> 32);
+  const unsigned rlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const unsigned rhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)rhi << 32) | rlo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const long long d = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)d, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(d >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
+}
+
+// Wave total in EVERY lane.  All 64 lanes must be active.  Fixed tree: pairs, quads, then the four quads of a row by two
+// row rotations (DPP: register-to-register, ~10 cycles a step -- the ds_bpermute shuffles this replaces cost ~150 cycles
+// a step, 0.3 us per reduction, which is most of a small-grid kernel's arithmetic time), then the four row totals read
+// from lanes 0 / 16 / 32 / 48 and added in row order.  Deterministic: the same sequence everywhere.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  return v;  // lane 0 holds the wave total
+  v += dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f64<0x124>(v);       // row_ror:4
+  v += dpp_f64<0x128>(v);       // row_ror:8
+  return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
 
 // Block total in thread 0 (deterministic: fixed shuffle tree, then waves in order).

@@ -15,6 +15,7 @@
 #include "mfs_cg_core.h"
 #include "mfs_pcg_apply.h"
 #include "mfs_pcg_slab.h"
+#include "mfs_pcg_resident.h"
 
 namespace mfs {
 
@@ -201,6 +202,11 @@ struct mfs_pcg3d {
   int fuse;                    // 1: native loop folds d = r + beta d into the stencil launch
   int lean;                    // mfs_pcg3d_iterate closes iteration j in the stencil launch of j + 1 (no reduction tail in the update): 1 / 0 / -1 auto
   unsigned char* cls;          // class byte per z-vector (compressed coefficient access)
+  int resident;                // small grids: the CG loop as one resident launch per batch (mfs_pcg_resident.h): 1 / 0 / -1 auto
+  int res_w;                   // its number of workgroups (MFS_RES_W, default 64)
+  ResPlan res;                 // decomposition (res.ok false: the grid does not qualify)
+  u64 *res_ar, *res_mirror;    // granule table of the dot products / mirror of the box faces of r (workspace)
+  unsigned res_epoch;          // episode tags handed out so far (monotonic over the engine's life)
   int compress;                // 1: per-iteration kernel skips the coefficient arrays of ZERO / REGULAR vectors
   int grid_apply, cus;
   int variant, xchunk, nt, bpc, nt_auto;   // apply-kernel tuning (mfs_pcg3d_tune)
@@ -350,7 +356,7 @@ size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   const int64_t n = gres[0] * gres[1] * gres[2];
   return core_ws_bytes() + 6 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096) +
-         align_up((size_t)kMaxPartials * 8, 4096);
+         align_up((size_t)kMaxPartials * 8, 4096) + res_ws_bytes(n, dtype_size(dt));
 }
 
 int64_t mfs_pcg3d_history_capacity(void) { return kHistCap; }
@@ -376,6 +382,16 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->asym = 0;
   h->cls = (unsigned char*)(p + 6 * cs);
   h->part_rz = (double*)(p + 6 * cs + align_up((size_t)h->n, 4096));
+  h->resident = env_int("MFS_RESIDENT", -1);
+  h->res_w = std::max(1, std::min(kResMaxW, env_int("MFS_RES_W", 64)));
+  h->res = ResPlan{};
+  h->res_ar = nullptr; h->res_mirror = nullptr; h->res_epoch = 0;
+  if (res_ws_bytes(h->n, h->c.elt) > 0) {
+    char* rp = (char*)h->part_rz + align_up((size_t)kMaxPartials * 8, 4096);
+    h->res_ar = (u64*)rp;
+    h->res_mirror = (u64*)(rp + align_up((size_t)kResRing * kResMaxW * 2 * 8, 4096));
+    h->res = res_plan(h->Nx, h->Ny, h->Nz, dt == MFS_F32 ? 4 : 2, h->c.elt, h->res_w);
+  }
   h->jacobi = env_int("MFS_JACOBI", 0);
   h->defer_x = env_int("MFS_DEFER_X", -1);
   h->x_owed = false;
@@ -504,6 +520,12 @@ int mfs_pcg3d_set_fuse(mfs_pcg3d* h, int on) {
 int mfs_pcg3d_set_defer_x(mfs_pcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
   h->defer_x = on < 0 ? -1 : (on != 0);
+  return MFS_OK;
+}
+
+int mfs_pcg3d_set_resident(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->resident = on < 0 ? -1 : (on != 0);
   return MFS_OK;
 }
 
@@ -646,6 +668,7 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
 }
 
 static bool native_fuse_ok(const mfs_pcg3d* h);
+static bool resident_ok(const mfs_pcg3d* h);
 // deferred x update: fused native loop, symmetric operator, prefetch depth 1, x 16-byte aligned
 static bool xdef_ok(const mfs_pcg3d* h) {
   // auto (< 0): on once the CG vectors no longer fit the Infinity Cache (256^3 fp32: 134.7 -> 130.2 us/iteration,
@@ -738,8 +761,64 @@ static int pcg_iterate_lean(mfs_pcg3d* h, int64_t n, hipStream_t st) {
   return MFS_OK;
 }
 
+// the resident loop (mfs_pcg_resident.h): a grid that fits W workgroups' registers, the fused loop's preconditions
+// (aligned vectors, compressed coefficient classes), no deferred x update pending
+static bool resident_ok(const mfs_pcg3d* h) {
+  return h->resident != 0 && h->res.ok && h->res_ar && native_fuse_ok(h) && !h->slab_loop && h->defer_x <= 0 &&
+         !h->x_owed && ((uintptr_t)h->c.x % 16 == 0);
+}
+
+extern "C++" {
+template <typename T, int VEC>
+static int pcg_launch_resident(mfs_pcg3d* h, const ResArgs& a, hipStream_t st) {
+  const ResPlan& p = h->res;
+#define MFS_RES(KVV)                                                                                              \
+  do {                                                                                                            \
+    if (h->asym) {                                                                                                \
+      MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_pcg_resident<T, VEC, KVV, true>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                   \
+      hipLaunchKernelGGL((k_pcg_resident<T, VEC, KVV, true>), dim3(p.W), dim3(kResBlock), p.lds, st, a);          \
+    } else {                                                                                                      \
+      MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_pcg_resident<T, VEC, KVV, false>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                   \
+      hipLaunchKernelGGL((k_pcg_resident<T, VEC, KVV, false>), dim3(p.W), dim3(kResBlock), p.lds, st, a);         \
+    }                                                                                                             \
+  } while (0)
+  if (p.kv <= 1) MFS_RES(1); else if (p.kv == 2) MFS_RES(2); else if (p.kv == 3) MFS_RES(3); else MFS_RES(4);
+#undef MFS_RES
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+}  // extern "C++"
+
+static int pcg_iterate_resident(mfs_pcg3d* h, int64_t n, hipStream_t st) {
+  while (n > 0) {
+    const int nb = (int)std::min<int64_t>(n, 1 << 20);
+    if (h->res_epoch > 0xf0000000u - 2u * (unsigned)nb) {          // tags about to wrap: start over on clean tables
+      MFS_HIP_TRY(hipMemsetAsync(h->res_ar, 0, res_ws_bytes(h->n, h->c.elt), st));
+      h->res_epoch = 0;
+    }
+    ResArgs a{};
+    a.x = h->c.x; a.r = h->c.r; a.q = h->c.q; a.dbuf[0] = h->c.d; a.dbuf[1] = h->d2;
+    a.diag = h->diag; a.cx = h->cx; a.cy = h->cy; a.cz = h->cz; a.cz2 = h->cz2; a.cls = h->cls;
+    a.Nx = h->Nx; a.Ny = h->Ny; a.Nz = h->Nz; a.Px = h->res.Px; a.Py = h->res.Py; a.bxm = h->res.bxm; a.bym = h->res.bym;
+    a.scal = h->c.scal; a.hist = h->c.hist; a.hist_cap = kHistCap;
+    a.j0 = h->c.iter_enq; a.n_iter = nb;
+    a.ar = h->res_ar; a.mirror = h->res_mirror;
+    a.tag0 = h->res_epoch + 1u;
+    a.timeout_ticks = (u64)std::max(1, env_int("MFS_RES_TIMEOUT_MS", 2000)) * 100000ull;   // wall clock: 100 MHz
+    int e = h->dt == MFS_F32 ? pcg_launch_resident<float, 4>(h, a, st) : pcg_launch_resident<double, 2>(h, a, st);
+    if (e) return e;
+    h->res_epoch += 2u * (unsigned)nb;
+    h->c.iter_enq += nb;
+    n -= nb;
+  }
+  return MFS_OK;
+}
+
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  if (!h->jacobi && resident_ok(h)) return pcg_iterate_resident(h, n, (hipStream_t)stream);
   if (!h->jacobi && lean_ok(h)) return pcg_iterate_lean(h, n, (hipStream_t)stream);
   if (h->jacobi) {
     const bool vec = core_vec_ok(h->c) && ((uintptr_t)h->diag % 16 == 0);
@@ -795,10 +874,12 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
   return core_poll(h->c, (hipStream_t)stream, iters, done, delta, alpha, beta);
 }
 
-// what the native loop will do for the engine as bound: bit 0 fused direction update, bit 1 deferred x update, bit 2 Jacobi
+// what the native loop will do for the engine as bound: bit 0 fused direction update, bit 1 deferred x update, bit 2 Jacobi,
+// bit 3 resident small-grid loop
 int mfs_pcg3d_loop_info(mfs_pcg3d* h) {
   if (!h || !h->c.x) return 0;
-  return (native_fuse_ok(h) ? 1 : 0) | (xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0);
+  const bool res = !h->jacobi && resident_ok(h);
+  return (native_fuse_ok(h) ? 1 : 0) | (!res && xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0) | (res ? 8 : 0);
 }
 
 // for callers that drive begin / iterate themselves: settles what the loop forms owe (the deferred x update, the

@@ -373,6 +373,10 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       cls_c = cls[base / VEC];
       cls_n = cls[(base + (x0 + 1 < x1 ? sx : 0)) / VEC];
     }
+    // this lane's first halo vector of plane x0 (requested with the rest of the batch, consumed when the image is staged)
+    RawVec<T, VEC> wh = {};
+    const bool h0 = LDS && tid < 2 * nzv;
+    if (h0) wh = src.raw((int64_t)x0 * sx + (tid < nzv ? m0 - Nz + tid * VEC : m0 + tile_len + (tid - nzv) * VEC));
     if (BOOK && book_pending) {                      // uniform over the workgroup: its first march
       book_pending = false;
       __shared__ double s_rr;
@@ -396,7 +400,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       // stage plane x0 (tile + halos) into buffer 0
       T* b0 = smem;
       if (active) vstore<T, VEC>(b0 + Nz + tid * VEC, vc);   // inactive lanes sit past tile_len = in the halo
-      for (int s = tid; s < 2 * nzv; s += kApplyBlock) {
+      if (h0) vstore<T, VEC>(b0 + (tid < nzv ? tid * VEC : Nz + tile_len + (tid - nzv) * VEC), src.fin(wh));
+      for (int s = tid + kApplyBlock; s < 2 * nzv; s += kApplyBlock) {
         const bool lo = s < nzv;
         const int j = lo ? s : s - nzv;
         vstore<T, VEC>(b0 + (lo ? j * VEC : Nz + tile_len + j * VEC),

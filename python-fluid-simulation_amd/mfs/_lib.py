@@ -94,6 +94,7 @@ SIGNATURES = {
     "mfs_pcg3d_set_jacobi": (_i, [_p, _i]),
     "mfs_pcg3d_set_defer_x": (_i, [_p, _i]),
     "mfs_pcg3d_set_lean": (_i, [_p, _i]),
+    "mfs_pcg3d_set_resident": (_i, [_p, _i]),
     "mfs_pcg3d_finish": (_i, [_p, _p]),
     "mfs_pcg3d_set_compress": (_i, [_p, _i]),
     "mfs_pcg3d_set_fuse": (_i, [_p, _i]),

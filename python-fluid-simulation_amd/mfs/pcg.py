@@ -54,7 +54,12 @@ class PcgEngine:
 
     def loop_info(self):
         b = int(self.lib.mfs_pcg3d_loop_info(self.h))
-        return dict(fused_direction_update=bool(b & 1), deferred_x_update=bool(b & 2), jacobi=bool(b & 4))
+        return dict(fused_direction_update=bool(b & 1), deferred_x_update=bool(b & 2), jacobi=bool(b & 4),
+                    resident=bool(b & 8))
+
+    def set_resident(self, on):
+        """small grids: run each batch of iterations as one resident launch (None = auto: whenever the grid fits)"""
+        _lib.check(self.lib.mfs_pcg3d_set_resident(self.h, -1 if on is None else int(bool(on))), "mfs_pcg3d_set_resident")
 
     def set_lean(self, on):
         """close each iteration at the top of the next stencil launch instead of in a reduction tail (None = auto)"""

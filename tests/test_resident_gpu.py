@@ -1,0 +1,129 @@
+"""The resident small-grid CG loop (csrc/mfs_pcg_resident.h: a whole batch of iterations in one launch, state in
+registers, dot products and box faces through self-validating records) against the launch-per-phase loop of the same
+engine and against the oracle.  The two loops do the same arithmetic per cell; they group the two dot products of an
+iteration differently, so they agree to rounding: the residual history to 1e-9 relative over the first dozen iterations
+in fp64 -- the bound the oracle comparisons use; 1e-11 is what the notebook-size grids show, a 175-cell system amplifies
+the last bit to 4e-10 by iteration 12 -- and 5e-5 in fp32 (the vectors themselves are rounded to 2^-24)."""
+import numpy as np
+import pytest
+import torch
+
+from mfs import scenes
+from oracle import mfs_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# the notebook's own grid, a cube, odd box splits (46 = 8 x 5.75), a grid smaller than the workgroup lattice, long rows
+SHAPES = [(48, 80, 48), (32, 32, 32), (20, 24, 36), (9, 7, 8), (3, 3, 4), (12, 70, 36), (40, 36, 32), (16, 16, 260)]
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def _run(gres, prec, resident, iters=12, check_every=5, seed=None, switch=False):
+    import solver.CGSolverBuffer as B
+    import solver.PressureCGSolver3D as P
+    seed = sum(gres) if seed is None else seed
+    sc = scenes.pressure_scene_3d(gres, seed=seed, vel_dtype=np.float32, solid_velocity=bool(seed & 1))
+    buf = B.CGSolverBuffer(gres, precision=prec, device=DEV)
+    s = P.PressureCGSolver3D(buf, gres, sc["bound_size"], check_every=check_every)
+    s.max_iter = iters
+    e = s._engine
+    e.set_resident(resident)
+    v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
+    try:
+        s.solve(*v, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]), tol=1e-30)
+    except ValueError:
+        pass
+    info = e.loop_info()
+    return dict(iters=s.iterations, hist=np.array(s.history), x=s.x.clone(), d=buf.d.clone(), r=buf.r.clone(),
+                q=buf.q.clone(), info=info, sc=sc)
+
+
+@pytest.mark.parametrize("gres", SHAPES)
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_resident_loop_matches_launch_per_phase_loop(gres, prec):
+    # a system of a few hundred unknowns is within a few iterations of finite termination after a dozen of them, where
+    # the last bit of a dot product grows tenfold per iteration (tools/res_debug.py 9 7 8: 1e-13 at iteration 6, 3e-5
+    # of the -- by then 200 times smaller -- residual at 12): compare those while the comparison still means something
+    iters = 12 if int(np.prod(gres)) >= 2000 else 6
+    a = _run(gres, prec, True, iters)
+    b = _run(gres, prec, False, iters)
+    assert not b["info"]["resident"]
+    if min(gres[0], gres[1]) >= 3 and gres[2] % (2 if prec == "fp64" else 4) == 0 and gres[2] >= (4 if prec == "fp64" else 8):
+        assert a["info"]["resident"], "the grid was expected to qualify for the resident loop"
+    assert a["iters"] == b["iters"]
+    rt = 1e-9 if prec == "fp64" else 5e-5
+    h0 = max(b["hist"][0], 1e-300)
+    np.testing.assert_allclose(a["hist"], b["hist"], rtol=rt, atol=1e-16 * h0)
+    for k in ("x", "d", "r", "q"):
+        ref = b[k]
+        scale = float(ref.abs().max()) or 1.0
+        err = float((a[k] - ref).abs().max())
+        assert err <= (1e-8 if prec == "fp64" else 2e-4) * scale, (k, err, scale)
+
+
+def test_resident_loop_against_the_oracle_history():
+    gres = (20, 24, 36)
+    a = _run(gres, "fp64", True)
+    sc = a["sc"]
+    ref = O.PressureCGSolver3D(gres, sc["bound_size"])
+    rv = [sc["vx"].copy(), sc["vy"].copy(), sc["vz"].copy()]
+    ref.solve(*rv, sc["sphi"], sc["sv"], sc["lphi"], tol=1e-30, max_iter=12, raise_on_fail=False)
+    n = min(len(a["hist"]), len(ref.history), 21)
+    np.testing.assert_allclose(a["hist"][:n], np.array(ref.history)[:n], rtol=1e-9)
+
+
+def test_batches_of_both_loops_follow_each_other():
+    """state handed over through the arrays and the scalar block: resident batch -> launch-per-phase batch -> resident"""
+    import solver.CGSolverBuffer as B
+    import solver.PressureCGSolver3D as P
+    import solver.SolidFraction3D as S
+    gres = (24, 20, 32)
+    sc = scenes.pressure_scene_3d(gres, seed=3, vel_dtype=np.float32)
+    out = []
+    for plan in ((True, False, True, False), (False, False, False, False)):
+        buf = B.CGSolverBuffer(gres, precision="fp64", device=DEV)
+        s = P.PressureCGSolver3D(buf, gres, sc["bound_size"])
+        e = s._engine
+        sphi, lphi = T(sc["sphi"]), T(sc["lphi"])
+        S.compute_solid_frac(gres, sphi, s.wx, s.wy, s.wz)
+        P.initialize_solver(s.cell_size, s._g, T(sc["vx"]), T(sc["vy"]), T(sc["vz"]), sphi, T(sc["sv"]), lphi, buf.b,
+                            s.wx, s.wy, s.wz)
+        e.setup(lphi, s.wx, s.wy, s.wz)
+        e.bind(buf.b, s.x, buf.d, buf.r, buf.q)
+        e.begin(0.0)
+        for res in plan:
+            e.set_resident(res)
+            e.iterate(3)
+        e.finish()
+        st = e.poll()
+        out.append((st["iterations"], np.array(e.history()), s.x.clone(), buf.d.clone(), buf.r.clone()))
+    assert out[0][0] == out[1][0] == 12
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-9)
+    for i in (2, 3, 4):
+        scale = float(out[1][i].abs().max()) or 1.0
+        assert float((out[0][i] - out[1][i]).abs().max()) <= 1e-8 * scale
+
+
+def test_resident_converging_solve_and_density_operator():
+    """a full solve to the default tolerance (early exit inside a batch) for the pressure and the density operator"""
+    import solver.CGSolverBuffer as B
+    import solver.PressureCGSolver3D as P
+    gres = (32, 40, 32)
+    sc = scenes.pressure_scene_3d(gres, seed=11, vel_dtype=np.float32)
+    res = []
+    for resident in (True, False):
+        buf = B.CGSolverBuffer(gres, precision="fp64", device=DEV)
+        s = P.PressureCGSolver3D(buf, gres, sc["bound_size"])
+        s._engine.set_resident(resident)
+        v = [T(sc["vx"]), T(sc["vy"]), T(sc["vz"])]
+        s.solve(*v, T(sc["sphi"]), T(sc["sv"]), T(sc["lphi"]), tol=1e-6)
+        res.append((s.iterations, s.x.clone(), [t.clone() for t in v]))
+    assert abs(res[0][0] - res[1][0]) <= 2
+    scale = float(res[1][1].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * scale
+    for a, b in zip(res[0][2], res[1][2]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30)
