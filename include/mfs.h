@@ -142,7 +142,9 @@ int mfs_pcg3d_set_resident(mfs_pcg3d* h, int on);
 /* synchronises `stream`, then reports the device-resident solver state. host call. */
 int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);
-/* begin + iterate/poll until done or max_iter; MFS_OK or MFS_NOT_CONVERGED. host-synchronous. */
+/* begin + iterate/poll until done or max_iter; MFS_OK or MFS_NOT_CONVERGED. host-synchronous.  check_every = iterations
+ * enqueued between two looks at the convergence flag (the resident small-grid loop, which stops by itself inside a
+ * batch, uses max(check_every, 128)). */
 int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_every,
                     mfs_stream stream, int64_t* iters_host);
 /* copies [delta0, dq1, delta1, dq2, delta2, ...] (first `cap` values) to the host; returns count or <0 */

@@ -901,7 +901,10 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   int done = 0;
   if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
   while (!done && enq < max_iter) {
-    const int64_t n = std::min(check_every, max_iter - enq);
+    // the resident loop stops by itself inside a batch (one launch), so a longer batch costs nothing but saves the
+    // launch, the reload of the state and the poll: at least 128 iterations per look there
+    const int64_t every = (!h->jacobi && resident_ok(h)) ? std::max<int64_t>(check_every, 128) : check_every;
+    const int64_t n = std::min(every, max_iter - enq);
     if (int e = mfs_pcg3d_iterate(h, n, stream)) return e;
     enq += n;
     if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;

@@ -180,6 +180,7 @@ k_pcg_resident(ResArgs a) {
   if (scal[S_DONE] != 0.0) return;                       // raised before this launch: uniform over the grid
   extern __shared__ __align__(16) unsigned char res_smem[];
   T* const img = reinterpret_cast<T*>(res_smem);
+  T* const rhalo = img + (size_t)(a.bxm + 2) * (a.bym + 2) * a.Nz;      // the neighbours' r on the halo, [nh] vectors
   __shared__ int s_fail;
   const int tid = threadIdx.x, W = gridDim.x;
   const int Nz = a.Nz, nzv = Nz / VEC;
@@ -271,6 +272,7 @@ k_pcg_resident(ResArgs a) {
   }
   double delta = scal[S_RING + (int)(j0 & 1)];
   const double tol2 = scal[S_TOL2];
+  const int64_t it0 = (int64_t)scal[S_ITERS];
   __syncthreads();
 
   int64_t jl = j0;                                       // the iteration whose d the registers hold at exit
@@ -335,9 +337,32 @@ k_pcg_resident(ResArgs a) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) xv[k][j] = (T)((double)xv[k][j] + alpha * (double)dv[k][j]);
     }
-    const double rr = res_allreduce_end(a.ar, W, tag + 1u, a.timeout_ticks, &ok);
+    // the neighbours' faces (published before their own r.r record, so waiting here cannot deadlock) -> LDS
+    bool hok = true;
+    for (int h = tid; h < nh; h += kResBlock) {
+      int g, l; bool own;
+      halo_of(h, &g, &l, &own);
+      if (!own) continue;
+      vec_t<T, VEC> rh;
+      if (!res_fetch<T, VEC>(mir, g, tag + 1u, a.timeout_ticks, &rh)) { hok = false; break; }
+      vstore<T, VEC>(rhalo + (size_t)h * VEC, rh);
+    }
+    if (!hok) s_fail = 1;
+    const double rr = res_allreduce_end(a.ar, W, tag + 1u, a.timeout_ticks, &ok);      // (its barrier publishes s_fail too)
     if (!ok) { if (tid == 0) slab_fail(scal, kErrArTimeout); break; }
-    if (blockIdx.x == 0 && tid == 0) cg_book(scal, a.hist, a.hist_cap, par, dq, rr);
+    if (s_fail) { if (tid == 0) slab_fail(scal, kErrHaloTimeout); break; }
+    if (blockIdx.x == 0 && tid == 0) {
+      // cg_book (mfs_cg_core.h) with its operands already in registers: stores only, nothing on this thread's path waits
+      const int64_t itc = it0 + it;
+      if (2 * itc + 2 < a.hist_cap) { a.hist[2 * itc + 1] = dq; a.hist[2 * itc + 2] = rr; }
+      scal[S_ITERS] = (double)(itc + 1);
+      scal[S_RING + (par ^ 1)] = rr;
+      scal[S_RR] = rr; scal[S_DQ] = dq; scal[S_DELTA] = delta; scal[S_LASTRR] = rr;
+      scal[S_ALPHA] = delta / dq;
+      if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
+      else if (rr < tol2) scal[S_DONE] = 1.0;
+      else scal[S_BETA] = rr / delta;
+    }
     if (cg_health(dq, rr) != 0 || rr < tol2 || it + 1 == a.n_iter) break;      // d_{j+1} is owed, as after every batch
     // ---- d = r + beta d: own vectors from registers, the halo from the neighbours' published r
     const double beta = rr / delta;
@@ -349,21 +374,17 @@ k_pcg_resident(ResArgs a) {
       for (int j = 0; j < VEC; ++j) dv[k][j] = (T)((double)rv[k][j] + beta * (double)dv[k][j]);
       vstore<T, VEC>(img + lofs[k], dv[k]);
     }
-    bool hok = true;
     for (int h = tid; h < nh; h += kResBlock) {
       int g, l; bool own;
       halo_of(h, &g, &l, &own);
       if (!own) continue;
-      vec_t<T, VEC> rh;
-      if (!res_fetch<T, VEC>(mir, g, tag + 1u, a.timeout_ticks, &rh)) { hok = false; break; }
+      const vec_t<T, VEC> rh = vload<T, VEC>(rhalo + (size_t)h * VEC);      // written by this very thread above
       vec_t<T, VEC> o = vload<T, VEC>(img + l);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] = (T)((double)rh[j] + beta * (double)o[j]);
       vstore<T, VEC>(img + l, o);
     }
-    if (!hok) s_fail = 1;
     __syncthreads();
-    if (s_fail) { if (tid == 0) slab_fail(scal, kErrHaloTimeout); break; }
   }
   // ---- state back to the arrays: x, r, q and d_jl (buffer jl & 1)
   if (!ran) return;
@@ -406,7 +427,7 @@ static inline ResPlan res_plan(int Nx, int Ny, int Nz, int vec, size_t elt, int 
     if (bxm < 1 || bym < 1) continue;
     const int64_t items = (int64_t)bxm * bym * nzv;
     const int kv = (int)((items + kResBlock - 1) / kResBlock);
-    const size_t lds = (size_t)(bxm + 2) * (bym + 2) * Nz * elt;
+    const size_t lds = ((size_t)(bxm + 2) * (bym + 2) + 2 * (size_t)(bxm + bym)) * Nz * elt;     // d image + the halo's r
     if (kv > 4 || lds > kResLdsMax) continue;
     const int64_t halo = (int64_t)bxm + bym;
     if (best_halo < 0 || halo < best_halo) {

@@ -42,6 +42,7 @@ def test_phase_loop_matches_native_loop(pg, name, overlap):
         b, x, d, r, q = T(g["b"]), *(torch.zeros(gres, dtype=torch.float64, device=DEV) for _ in range(4))
         eng.bind(b, x, d, r, q)
         if mode == "native":
+            eng.set_resident(False)     # the launch-per-phase loop (the resident small-grid loop has tests/test_resident_gpu.py)
             ok, it = eng.solve(float(g["tol"]), int(np.prod(gres)), 16)
             assert ok
         else:

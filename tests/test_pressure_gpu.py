@@ -323,6 +323,7 @@ def test_fused_direction_update_is_bit_identical(mods, name, prec):
         buf = B.CGSolverBuffer(gres, precision=prec, device=DEV)
         s = P.PressureCGSolver3D(buf, gres, g["bound_size"], check_every=5)
         s._engine.set_fuse(fuse)
+        s._engine.set_resident(False)     # both launch-per-phase forms (the resident loop: tests/test_resident_gpu.py)
         v = [T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])]
         s.solve(*v, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), tol=float(g["tol"]))
         res.append((s.iterations, s.history, s.x.clone(), buf.d.clone(), buf.r.clone(), buf.q.clone(), v))
