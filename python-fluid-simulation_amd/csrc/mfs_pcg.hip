@@ -389,7 +389,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   if (res_ws_bytes(h->n, h->c.elt) > 0) {
     char* rp = (char*)h->part_rz + align_up((size_t)kMaxPartials * 8, 4096);
     h->res_ar = (u64*)rp;
-    h->res_mirror = (u64*)(rp + align_up((size_t)kResRing * kResMaxW * 2 * 8, 4096));
+    h->res_mirror = (u64*)(rp + align_up((size_t)kResRing * kResMaxW * kResRecStrideMax * 8, 4096));
     h->res = res_plan(h->Nx, h->Ny, h->Nz, dt == MFS_F32 ? 4 : 2, h->c.elt, h->res_w);
   }
   h->jacobi = env_int("MFS_JACOBI", 0);
@@ -805,6 +805,7 @@ static int pcg_iterate_resident(mfs_pcg3d* h, int64_t n, hipStream_t st) {
     a.scal = h->c.scal; a.hist = h->c.hist; a.hist_cap = kHistCap;
     a.j0 = h->c.iter_enq; a.n_iter = nb;
     a.ar = h->res_ar; a.mirror = h->res_mirror;
+    a.rec_stride = std::max(2, std::min(kResRecStrideMax, env_int("MFS_RES_REC_STRIDE", 64) & ~1));   // u64 words between records (512 B: one record per memory line pair; 16-byte stride costs 0.4 us per iteration)
     a.tag0 = h->res_epoch + 1u;
     a.timeout_ticks = (u64)std::max(1, env_int("MFS_RES_TIMEOUT_MS", 2000)) * 100000ull;   // wall clock: 100 MHz
     int e = h->dt == MFS_F32 ? pcg_launch_resident<float, 4>(h, a, st) : pcg_launch_resident<double, 2>(h, a, st);

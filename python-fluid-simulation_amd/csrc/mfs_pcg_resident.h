@@ -44,6 +44,15 @@ constexpr int kResMaxW = 64;
 constexpr int kResRing = 4;
 constexpr int64_t kResMaxCells = 1 << 20;          // grids beyond this never qualify (mirror sizing)
 constexpr size_t kResLdsMax = 150 * 1024;
+constexpr int kResRecStrideMax = 1024;             // u64 words between two workgroups' records (8 KiB), at most
+
+// measurement build only (tools/build_variant.sh NAME -DMFS_RES_STAMP): workgroup 0 accumulates the wall-clock span of
+// every phase of the loop and prints the averages when the launch ends
+#ifdef MFS_RES_STAMP
+#define RES_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const u64 t_ = wall_clock64(); st_acc[i] += t_ - st_last; st_last = t_; } } while (0)
+#else
+#define RES_STAMP(i) do { } while (0)
+#endif
 
 struct ResArgs {
   void *x, *r, *q, *dbuf[2];
@@ -55,7 +64,8 @@ struct ResArgs {
   int64_t hist_cap;
   int64_t j0;
   int n_iter;
-  u64* ar;                                          // [kResRing][kResMaxW][2] granules
+  u64* ar;                                          // [kResRing][kResMaxW] records of 2 granules, `rec_stride` u64 apart
+  int rec_stride;
   u64* mirror;                                      // [2][n * Gran<T>::N] granules: r of the box faces, by global cell index
   unsigned tag0;                                    // first episode tag of this launch (>= 1; 2 per iteration)
   u64 timeout_ticks;
@@ -64,79 +74,96 @@ struct ResArgs {
 __device__ __forceinline__ u64 dev_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void dev_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// both granules of a record in ONE request (a torn 16-byte read is harmless: each half validates itself)
+typedef unsigned long long res_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ res_u64x2 dev_load2(const u64* p) {
+  res_u64x2 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 // A dot product in two halves, so that work which does not need the total can sit between them.
 // begin: workgroup sum (fixed order) -> this workgroup's record in the table.
-__device__ __forceinline__ void res_allreduce_begin(double v, u64* ar, unsigned tag) {
+__device__ __forceinline__ void res_allreduce_begin(double v, u64* ar, int rec_stride, unsigned tag) {
   __shared__ double s_w[kResBlock / kWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   v = wave_sum(v);
   if (lane == 0) s_w[wave] = v;
-  __syncthreads();
+  MFS_LDS_BARRIER();            // only LDS is shared inside the workgroup: stores to the mirror / arrays stay in flight
   if (wave == 0 && lane == 0) {
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kResBlock / kWave; ++w) t += s_w[w];
-    u64* tab = ar + (size_t)(tag % kResRing) * kResMaxW * 2;
+    u64* tab = ar + ((size_t)(tag % kResRing) * kResMaxW + blockIdx.x) * rec_stride;
     const u64 bits = (u64)__double_as_longlong(t);
-    dev_store(tab + 2 * blockIdx.x + 0, ((u64)tag << 32) | (bits & 0xffffffffull));
-    dev_store(tab + 2 * blockIdx.x + 1, ((u64)tag << 32) | (bits >> 32));
+    dev_store(tab + 0, ((u64)tag << 32) | (bits & 0xffffffffull));
+    dev_store(tab + 1, ((u64)tag << 32) | (bits >> 32));
   }
 }
 
 // end: the first wave polls the W records (a lane each) and adds them in one fixed tree -- every workgroup holds the
 // bit-identical total; known to every thread on return.  *ok false on timeout.  The first polls read no clock (a
 // clock read is itself a memory-latency operation; records normally land within a poll or two).
-__device__ __forceinline__ double res_allreduce_end(u64* ar, int W, unsigned tag, u64 timeout_ticks, bool* ok) {
+__device__ __forceinline__ double res_allreduce_end(u64* ar, int rec_stride, int W, unsigned tag, u64 timeout_ticks, bool* ok) {
   __shared__ double s_tot;
   __shared__ int s_ok;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (wave == 0) {
-    const u64* tab = ar + (size_t)(tag % kResRing) * kResMaxW * 2;
     double c = 0.0;
     bool good = true;
     if (lane < W) {
-      const u64* g = tab + 2 * lane;
-      u64 lo = dev_load(g), hi = dev_load(g + 1);
-      bool got = (lo >> 32) == tag && (hi >> 32) == tag;
+      const u64* g = ar + ((size_t)(tag % kResRing) * kResMaxW + lane) * rec_stride;
+      res_u64x2 w = dev_load2(g);
+      bool got = (w[0] >> 32) == tag && (w[1] >> 32) == tag;
       for (int spin = 0; spin < 64 && !got; ++spin) {
-        lo = dev_load(g); hi = dev_load(g + 1);
-        got = (lo >> 32) == tag && (hi >> 32) == tag;
+        w = dev_load2(g);
+        got = (w[0] >> 32) == tag && (w[1] >> 32) == tag;
       }
       if (!got) {
         const u64 t0 = wall_clock64();
         for (;;) {
           __builtin_amdgcn_s_sleep(1);
-          lo = dev_load(g); hi = dev_load(g + 1);
-          if ((lo >> 32) == tag && (hi >> 32) == tag) break;
+          w = dev_load2(g);
+          if ((w[0] >> 32) == tag && (w[1] >> 32) == tag) break;
           if (wall_clock64() - t0 > timeout_ticks) { good = false; break; }
         }
       }
-      c = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+      c = __longlong_as_double((long long)((w[1] << 32) | (w[0] & 0xffffffffull)));
     }
     good = __all(good);
     c = wave_sum(c);                                   // the same tree in every workgroup
     if (lane == 0) { s_tot = c; s_ok = good ? 1 : 0; }
   }
-  __syncthreads();
+  MFS_LDS_BARRIER();
   *ok = s_ok != 0;
   return s_tot;
 }
 
 // r of one z-vector as tagged granules (agent scope), and back
+__device__ __forceinline__ void dev_store2(u64* p, u64 a, u64 b) {
+  // 16-byte write-through store of TWO granules (a store torn between its halves is harmless: each validates itself).
+  // The trailing s_nop is part of the instruction's contract -- see sys_store2 in mfs_p2p.h.
+  res_u64x2 v = {a, b};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void res_publish(u64* buf, int64_t elem, vec_t<T, VEC> v, unsigned tag) {
   const u64 t = (u64)tag << 32;
   u64* g = buf + elem * Gran<T>::N;
+  u64 w[VEC * Gran<T>::N];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     if (Gran<T>::N == 1) {
-      dev_store(g + j, t | (u64)__float_as_uint((float)v[j]));
+      w[j] = t | (u64)__float_as_uint((float)v[j]);
     } else {
       const u64 bits = (u64)__double_as_longlong((double)v[j]);
-      dev_store(g + 2 * j, t | (bits & 0xffffffffull));
-      dev_store(g + 2 * j + 1, t | (bits >> 32));
+      w[2 * j] = t | (bits & 0xffffffffull);
+      w[2 * j + 1] = t | (bits >> 32);
     }
   }
+#pragma unroll
+  for (int k = 0; k < VEC * Gran<T>::N; k += 2) dev_store2(g + k, w[k], w[k + 1]);      // elem is a multiple of VEC: 16-byte aligned
 }
 
 template <typename T, int VEC>
@@ -277,7 +304,15 @@ k_pcg_resident(ResArgs a) {
 
   int64_t jl = j0;                                       // the iteration whose d the registers hold at exit
   bool ran = false;
+#ifdef MFS_RES_STAMP
+  u64 st_acc[10] = {}, st_last = wall_clock64();
+  int st_n = 0;
+#endif
   for (int it = 0; it < a.n_iter; ++it) {
+#ifdef MFS_RES_STAMP
+    ++st_n;
+#endif
+    RES_STAMP(9);
     const int64_t jj = j0 + it;
     const int par = (int)(jj & 1);
     const unsigned tag = a.tag0 + 2u * (unsigned)it;
@@ -314,8 +349,11 @@ k_pcg_resident(ResArgs a) {
       }
     }
     bool ok;
-    res_allreduce_begin(acc, a.ar, tag);
-    const double dq = res_allreduce_end(a.ar, W, tag, a.timeout_ticks, &ok);
+    RES_STAMP(0);
+    res_allreduce_begin(acc, a.ar, a.rec_stride, tag);
+    RES_STAMP(1);
+    const double dq = res_allreduce_end(a.ar, a.rec_stride, W, tag, a.timeout_ticks, &ok);
+    RES_STAMP(2);
     if (!ok) { if (tid == 0) slab_fail(scal, kErrArTimeout); break; }
     // ---- r -= alpha q ; r.r ; faces of r -> mirror ; then, while the r.r records travel, x += alpha d
     const double alpha = delta / dq;
@@ -329,15 +367,22 @@ k_pcg_resident(ResArgs a) {
         rv[k][j] = (T)((double)rv[k][j] - alpha * (double)qv[k][j]);
         acc += (double)rv[k][j] * (double)rv[k][j];
       }
-      if (flags[k] & 8u) res_publish<T, VEC>(mir, gofs[k], rv[k], tag + 1u);
     }
-    res_allreduce_begin(acc, a.ar, tag + 1u);
+    RES_STAMP(3);
+    res_allreduce_begin(acc, a.ar, a.rec_stride, tag + 1u);
+    RES_STAMP(4);
+    // faces after the record HAS BEEN ISSUED (second barrier: the other waves do not overtake wave 0): their
+    // write-through stores take a microsecond to drain, and a record queued behind them is a microsecond late everywhere
+    MFS_LDS_BARRIER();
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+      if ((flags[k] & 9u) == 9u) res_publish<T, VEC>(mir, gofs[k], rv[k], tag + 1u);
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) xv[k][j] = (T)((double)xv[k][j] + alpha * (double)dv[k][j]);
     }
-    // the neighbours' faces (published before their own r.r record, so waiting here cannot deadlock) -> LDS
+    // the neighbours' faces (published without waiting for anybody, so waiting for them here cannot deadlock) -> LDS
     bool hok = true;
     for (int h = tid; h < nh; h += kResBlock) {
       int g, l; bool own;
@@ -348,7 +393,8 @@ k_pcg_resident(ResArgs a) {
       vstore<T, VEC>(rhalo + (size_t)h * VEC, rh);
     }
     if (!hok) s_fail = 1;
-    const double rr = res_allreduce_end(a.ar, W, tag + 1u, a.timeout_ticks, &ok);      // (its barrier publishes s_fail too)
+    RES_STAMP(5);
+    const double rr = res_allreduce_end(a.ar, a.rec_stride, W, tag + 1u, a.timeout_ticks, &ok);      // (its barrier publishes s_fail too)
     if (!ok) { if (tid == 0) slab_fail(scal, kErrArTimeout); break; }
     if (s_fail) { if (tid == 0) slab_fail(scal, kErrHaloTimeout); break; }
     if (blockIdx.x == 0 && tid == 0) {
@@ -363,6 +409,7 @@ k_pcg_resident(ResArgs a) {
       else if (rr < tol2) scal[S_DONE] = 1.0;
       else scal[S_BETA] = rr / delta;
     }
+    RES_STAMP(6);
     if (cg_health(dq, rr) != 0 || rr < tol2 || it + 1 == a.n_iter) break;      // d_{j+1} is owed, as after every batch
     // ---- d = r + beta d: own vectors from registers, the halo from the neighbours' published r
     const double beta = rr / delta;
@@ -384,8 +431,17 @@ k_pcg_resident(ResArgs a) {
       for (int j = 0; j < VEC; ++j) o[j] = (T)((double)rh[j] + beta * (double)o[j]);
       vstore<T, VEC>(img + l, o);
     }
-    __syncthreads();
+    RES_STAMP(7);
+    MFS_LDS_BARRIER();
+    RES_STAMP(8);
   }
+#ifdef MFS_RES_STAMP
+  if (blockIdx.x == 0 && tid == 0 && st_n > 100)
+    printf("resident stamps, ns per iteration over %d: stencil %.0f | begin1 %.0f | end1 %.0f | r+publish %.0f | begin2 %.0f | x+halo fetch %.0f | end2 %.0f | d+halo %.0f | barrier %.0f | loop top %.0f\n",
+           st_n, 10.0 * st_acc[0] / st_n, 10.0 * st_acc[1] / st_n, 10.0 * st_acc[2] / st_n, 10.0 * st_acc[3] / st_n,
+           10.0 * st_acc[4] / st_n, 10.0 * st_acc[5] / st_n, 10.0 * st_acc[6] / st_n, 10.0 * st_acc[7] / st_n,
+           10.0 * st_acc[8] / st_n, 10.0 * st_acc[9] / st_n);
+#endif
   // ---- state back to the arrays: x, r, q and d_jl (buffer jl & 1)
   if (!ran) return;
   T* const dout = (T*)a.dbuf[jl & 1];
@@ -441,7 +497,7 @@ static inline ResPlan res_plan(int Nx, int Ny, int Nz, int vec, size_t elt, int 
 static inline size_t res_ws_bytes(int64_t n, size_t elt) {
   if (n > kResMaxCells) return 0;
   const size_t gran = elt == 4 ? 1 : 2;
-  return align_up((size_t)kResRing * kResMaxW * 2 * 8, 4096) + align_up(2 * (size_t)n * gran * 8, 4096);
+  return align_up((size_t)kResRing * kResMaxW * kResRecStrideMax * 8, 4096) + align_up(2 * (size_t)n * gran * 8, 4096);
 }
 
 }  // namespace mfs
