@@ -301,9 +301,12 @@ __global__ void __launch_bounds__(kVmBlock, WAVES)
 k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
                   int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
                   const double* __restrict__ done_flag) {
-  if (done_flag && *done_flag != 0.0) return;
+  // the flag is REQUESTED here and tested where the first march's own loads have been issued: on a small grid the
+  // launch is a chain of memory round trips, and flag -> planes was two of them (loads past a raised flag are harmless)
+  const double dn = done_flag ? *done_flag : 0.0;
   double acc = 0.0;
   if ((int)blockIdx.x >= gmain) {
+    if (dn != 0.0) return;
     const int b = (int)blockIdx.x - gmain, g2 = (int)gridDim.x - gmain - g0 - g1;
     if (b < g0) acc = vcg_slab_rows<T, 0, false>(c, k1, k2, v, ox, b0, b, g0);
     else if (b < g0 + g1) acc = vcg_slab_rows<T, 1, false>(c, k1, k2, v, oy, b1, b - g0, g1);
@@ -409,6 +412,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     // ---- prologue: the images of planes x0-1, x0, x0+1 into ring slots 0, 1, 2; the volume samples of the first step
     {
       const Plane pa = fetch(x0 - 1), pb = fetch(x0), pc = fetch(x0 + 1);
+      if (dn != 0.0) return;                                   // uniform over the grid
       publish(smem, pa); publish(smem + BUF, pb); publish(smem + 2 * BUF, pc);
       const T* const q = C1 + (int64_t)x0 * sc + o_c;          // class 1 of this vector; class p at q + (p-1)*cs
       rg.cm = vload<T, VEC>(q + 6 * cs - sc);

@@ -186,6 +186,8 @@ def load():
             "There is no CPU fallback for the solver path.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("MFS_LIB") and not hasattr(lib, name):
+            continue                     # an older A/B build of the ABI (tools/, MFS_LIB only): newer entry points absent
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
