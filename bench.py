@@ -193,6 +193,34 @@ def f64_leg(args, torch, dev, lgres, seed):
     return out
 
 
+def notebook_grid_leg(torch, dev):
+    """the reference's OWN grid (3D_viscous_fluid_sim.ipynb: 48 x 80 x 48, the drop-in's default fp64 state): a launch-bound
+    size, where the loop runs as one resident launch per batch (csrc/mfs_pcg_resident.h).  Time per CG iteration, and the
+    first 10 iterations against the C oracle like every other leg."""
+    from mfs.pcg import PcgEngine
+    gres = (48, 80, 48)
+    wx, wy, wz, lphi, (b, x, d, r, q) = build_problem(torch, dev, torch.float64, gres, gres, 5, None)
+    eng = PcgEngine(gres, torch.float64, dev)
+    eng.setup(lphi, wx, wy, wz)
+    eng.bind(b, x, d, r, q)
+    eng.begin(0.0)
+    eng.iterate(100)
+    torch.cuda.synchronize()
+    n = 2000
+    t0 = time.perf_counter()
+    eng.iterate(n)
+    eng.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.poll()
+    info = eng.loop_info()
+    assert st["iterations"] == n + 100 and st["delta"] == st["delta"], st
+    import argparse
+    pc = parity_check(argparse.Namespace(), torch, dev, torch.float64, gres, 5)
+    return {"grid": list(gres), "dtype": "f64", "loop": "resident" if info.get("resident") else "launch-per-phase",
+            "us_per_iteration": round(dt / n * 1e6, 2), "iters_per_s": round(n / dt, 1), "parity_check": pc}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks as child processes
     (one per GPU, `python -m torch.distributed.run`), relay their output -- rank 0 prints the JSON line -- and return
@@ -402,6 +430,7 @@ def main():
     rf = None
     parity = None
     f64_line = None
+    nb_line = None
     if rank == 0 and not args.timed_loop_only:
         Nx, Ny, Nz = lgres
         cells_l = Nx * Ny * Nz
@@ -532,6 +561,9 @@ def main():
         # ---- the drop-in's DEFAULT precision (fp64 state, like the reference): same workload, shorter timed loop
         if world == 1 and transport == "single" and args.dtype == "f32" and not args.no_f64_line:
             f64_line = f64_leg(args, torch, dev, lgres, seed)
+        # ---- the reference's own grid (launch-bound size): resident loop
+        if world == 1 and transport == "single" and not args.no_f64_line:
+            nb_line = notebook_grid_leg(torch, dev)
     if world > 1:
         dist.barrier()
 
@@ -567,6 +599,8 @@ def main():
             out["parity_check"] = parity
         if f64_line is not None:
             out["f64_state"] = f64_line
+        if nb_line is not None:
+            out["notebook_grid"] = nb_line
         if shared:
             out["rehearsal"] = "all ranks share cuda:0 over gloo (MFS_BENCH_SHARED_GPU=1): code-path check, not a measurement"
         if tinfo:
