@@ -45,7 +45,8 @@ enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TO
        S_ERR = MFS_PCG_S_ERR /* != 0: the solve was stopped -- 1 / 2 a peer-to-peer wait timed out (slab loop: all-reduce /
                                 halo plane), 3 d.q == 0 (the reference's ZeroDivisionError, PressureCGSolver3D.py:211),
                                 4 a non-finite d.q or r.r (the reference would spin to max_iter on `nan < tol**2`) */ };
-enum { kErrArTimeout = 1, kErrHaloTimeout = 2, kErrZeroDq = 3, kErrNonFinite = 4 };
+enum { kErrArTimeout = 1, kErrHaloTimeout = 2, kErrZeroDq = 3, kErrNonFinite = 4,
+       kErrNotResident = 5 };   // resident loop: its workgroups did not all show up for the FIRST dot product of a launch (nothing written)
 
 // health of the two dot products that close an iteration: 0 fine, else the S_ERR code.  Detected on the device so that
 // a poisoned solve stops within one `check_every` instead of iterating to max_iter = prod(gres).
@@ -699,7 +700,8 @@ static inline int core_poll(CgCore& c, hipStream_t st, int64_t* iters, int* done
                 (long long)c.pinned[S_ITERS]);
       return MFS_E_NONFINITE;
     }
-    set_error("peer-to-peer wait timed out inside the CG loop (code %d: 1 = all-reduce, 2 = halo plane)", code);
+    set_error("a bounded wait timed out inside the CG loop (code %d: 1 = dot-product exchange, 2 = halo exchange, 5 = the resident "
+              "small-grid loop could not get its workgroups co-resident -- MFS_RESIDENT=0 selects the launch-per-phase loop)", code);
     return MFS_E_TIMEOUT;
   }
   if (iters) *iters = (int64_t)c.pinned[S_ITERS];

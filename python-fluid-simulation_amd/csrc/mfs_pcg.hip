@@ -808,6 +808,8 @@ static int pcg_iterate_resident(mfs_pcg3d* h, int64_t n, hipStream_t st) {
     a.rec_stride = std::max(2, std::min(kResRecStrideMax, env_int("MFS_RES_REC_STRIDE", 64) & ~1));   // u64 words between records (512 B: one record per memory line pair; 16-byte stride costs 0.4 us per iteration)
     a.tag0 = h->res_epoch + 1u;
     a.timeout_ticks = (u64)std::max(1, env_int("MFS_RES_TIMEOUT_MS", 2000)) * 100000ull;   // wall clock: 100 MHz
+    a.first_timeout_ticks = (u64)std::max(1, env_int("MFS_RES_FIRST_TIMEOUT_MS", 250)) * 100000ull;
+    a.test_drop_wg = env_int("MFS_RES_TEST_DROP_WG", -1);
     int e = h->dt == MFS_F32 ? pcg_launch_resident<float, 4>(h, a, st) : pcg_launch_resident<double, 2>(h, a, st);
     if (e) return e;
     h->res_epoch += 2u * (unsigned)nb;
@@ -872,7 +874,20 @@ static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t s
 int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, double* delta, double* alpha,
                    double* beta) {
   MFS_REQUIRE(h, "null handle");
-  return core_poll(h->c, (hipStream_t)stream, iters, done, delta, alpha, beta);
+  hipStream_t st = (hipStream_t)stream;
+  // The resident loop did not get its workgroups together (a shared GPU): that launch -- and every launch queued behind
+  // it -- wrote nothing, so the state is the one the scalar block describes.  Clear the flag, switch this engine to the
+  // launch-per-phase loop for good, and report the iterations that did complete: the caller (mfs_pcg3d_solve does) goes on
+  // from there.
+  MFS_HIP_TRY(hipMemcpyAsync(h->c.pinned, h->c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
+  MFS_HIP_TRY(hipStreamSynchronize(st));
+  if ((int)h->c.pinned[S_ERR] == kErrNotResident) {
+    MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_ERR, 0, sizeof(double), st));
+    MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_DONE, 0, sizeof(double), st));
+    h->resident = 0;
+    h->c.iter_enq = (int64_t)h->c.pinned[S_ITERS];
+  }
+  return core_poll(h->c, st, iters, done, delta, alpha, beta);
 }
 
 // what the native loop will do for the engine as bound: bit 0 fused direction update, bit 1 deferred x update, bit 2 Jacobi,
@@ -907,8 +922,8 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
     const int64_t every = (!h->jacobi && resident_ok(h)) ? std::max<int64_t>(check_every, 128) : check_every;
     const int64_t n = std::min(every, max_iter - enq);
     if (int e = mfs_pcg3d_iterate(h, n, stream)) return e;
-    enq += n;
     if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+    enq = h->c.iter_enq;        // = enq + n, unless the poll has just taken a batch back (resident loop not resident)
   }
   if (int e = pcg_home_d(h, iters, done != 0, (hipStream_t)stream)) return e;
   if (iters_host) *iters_host = iters;

@@ -24,7 +24,11 @@
 //   * bookkeeping (convergence test :218, history, beta :220) is cg_book of mfs_cg_core.h, run by workgroup 0.
 //
 // Every wait is a bounded spin; a timeout raises the engine's error word (kErrArTimeout / kErrHaloTimeout), all
-// workgroups leave, the host reports MFS_E_TIMEOUT.  Workgroups never wait for anything a peer publishes AFTER
+// workgroups leave WITHOUT writing their state back, the host reports MFS_E_TIMEOUT.  The one timeout that can happen on
+// healthy hardware -- a GPU shared with other work does not give the launch all its workgroups at once -- shows at the
+// very first dot product of a launch, before anything has been written anywhere: it raises kErrNotResident instead
+// (short bound, `first_timeout_ticks`), and mfs_pcg3d_poll turns that into "this engine uses the launch-per-phase loop
+// from now on" -- arrays and scalar block are exactly as they were before the launch.  Workgroups never wait for anything a peer publishes AFTER
 // waiting itself for them within the same episode, so the launch cannot deadlock as long as all W workgroups get a
 // CU -- W <= 64 of 256, one workgroup per CU by LDS size; nothing else runs on the stream.
 //
@@ -68,7 +72,8 @@ struct ResArgs {
   int rec_stride;
   u64* mirror;                                      // [2][n * Gran<T>::N] granules: r of the box faces, by global cell index
   unsigned tag0;                                    // first episode tag of this launch (>= 1; 2 per iteration)
-  u64 timeout_ticks;
+  u64 timeout_ticks, first_timeout_ticks;
+  int test_drop_wg;                                 // fault injection (MFS_RES_TEST_DROP_WG): this workgroup never shows up; -1 none
 };
 
 __device__ __forceinline__ u64 dev_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -205,6 +210,7 @@ __global__ void __launch_bounds__(kResBlock, 2)
 k_pcg_resident(ResArgs a) {
   double* const scal = a.scal;
   if (scal[S_DONE] != 0.0) return;                       // raised before this launch: uniform over the grid
+  if ((int)blockIdx.x == a.test_drop_wg) return;
   extern __shared__ __align__(16) unsigned char res_smem[];
   T* const img = reinterpret_cast<T*>(res_smem);
   T* const rhalo = img + (size_t)(a.bxm + 2) * (a.bym + 2) * a.Nz;      // the neighbours' r on the halo, [nh] vectors
@@ -352,9 +358,9 @@ k_pcg_resident(ResArgs a) {
     RES_STAMP(0);
     res_allreduce_begin(acc, a.ar, a.rec_stride, tag);
     RES_STAMP(1);
-    const double dq = res_allreduce_end(a.ar, a.rec_stride, W, tag, a.timeout_ticks, &ok);
+    const double dq = res_allreduce_end(a.ar, a.rec_stride, W, tag, it == 0 ? a.first_timeout_ticks : a.timeout_ticks, &ok);
     RES_STAMP(2);
-    if (!ok) { if (tid == 0) slab_fail(scal, kErrArTimeout); break; }
+    if (!ok) { if (tid == 0) slab_fail(scal, it == 0 ? kErrNotResident : kErrArTimeout); ran = false; break; }
     // ---- r -= alpha q ; r.r ; faces of r -> mirror ; then, while the r.r records travel, x += alpha d
     const double alpha = delta / dq;
     u64* const mir = a.mirror + (size_t)par * (size_t)a.Nx * sx * Gran<T>::N;
@@ -395,8 +401,8 @@ k_pcg_resident(ResArgs a) {
     if (!hok) s_fail = 1;
     RES_STAMP(5);
     const double rr = res_allreduce_end(a.ar, a.rec_stride, W, tag + 1u, a.timeout_ticks, &ok);      // (its barrier publishes s_fail too)
-    if (!ok) { if (tid == 0) slab_fail(scal, kErrArTimeout); break; }
-    if (s_fail) { if (tid == 0) slab_fail(scal, kErrHaloTimeout); break; }
+    if (!ok) { if (tid == 0) slab_fail(scal, kErrArTimeout); ran = false; break; }
+    if (s_fail) { if (tid == 0) slab_fail(scal, kErrHaloTimeout); ran = false; break; }
     if (blockIdx.x == 0 && tid == 0) {
       // cg_book (mfs_cg_core.h) with its operands already in registers: stores only, nothing on this thread's path waits
       const int64_t itc = it0 + it;
@@ -484,7 +490,9 @@ static inline ResPlan res_plan(int Nx, int Ny, int Nz, int vec, size_t elt, int 
     const int64_t items = (int64_t)bxm * bym * nzv;
     const int kv = (int)((items + kResBlock - 1) / kResBlock);
     const size_t lds = ((size_t)(bxm + 2) * (bym + 2) + 2 * (size_t)(bxm + bym)) * Nz * elt;     // d image + the halo's r
-    if (kv > 4 || lds > kResLdsMax) continue;
+    // registers: 4 vectors per thread fit (with spills that cost little) for 4-byte state; for 8-byte state the fourth
+    // makes the loop slower than the launch-per-phase one (64^3: 11.8 vs 11.4 us per iteration)
+    if (kv > (elt == 4 ? 4 : 3) || lds > kResLdsMax) continue;
     const int64_t halo = (int64_t)bxm + bym;
     if (best_halo < 0 || halo < best_halo) {
       best_halo = halo;
