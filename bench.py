@@ -492,8 +492,12 @@ def main():
             torch.cuda.synchronize()
             ms_b2b = s_ev.elapsed_time(e_ev) / reps
         achieved = alg_bytes / (ms_cg * 1e-3) / 1e9
-        kname = ("k_pcg_apply_march<..., FUSE=true, XDEF=true> (stencil apply + d = r + beta d + x += alpha d_old)"
-                 if form["deferred_x_update"] else "k_pcg_apply_march<..., FUSE=true> (stencil apply + d = r + beta d)")
+        # the launch the timed loop runs: since round 2 it also closes the previous iteration (folds the r.r partials, takes
+        # the convergence decision; template flag BOOK) -- native_apply / native_finish are the two halves of exactly that loop
+        kname = ("k_pcg_apply_march<..., FUSE=true, XDEF=true, BOOK=true> (stencil apply + d = r + beta d + x += alpha d_old "
+                 "+ bookkeeping of the previous iteration)"
+                 if form["deferred_x_update"] else "k_pcg_apply_march<..., FUSE=true, BOOK=true> (stencil apply + d = r + beta d "
+                 "+ bookkeeping of the previous iteration)")
         # HBM bytes per launch from PMC counters: collected by tools/pmc_bench.sh on this same command in a SEPARATE
         # run (rocprofv3 --pmc passes cannot ride in a timed run) and committed under profiles/ -- evidence, not a
         # measurement of this run; valid for the default workload only.  traffic_frac = those bytes / this run's kernel

@@ -115,8 +115,10 @@ int mfs_pcg3d_bind(mfs_pcg3d* h, void* b, void* x, void* d, void* r, void* q);
 int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream);
 /* enqueue n CG iterations (lines 207-221); iterations after convergence are device-side no-ops */
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream);
-/* the two halves of ONE iteration of mfs_pcg3d_iterate (so a caller can bracket the stencil launch
- * with events): the stencil launch, then the x/r update and the direction update / its bookkeeping */
+/* the two halves of ONE iteration of mfs_pcg3d_iterate's launch-per-phase loop (so a caller can bracket the stencil launch
+ * with events): the stencil launch, then the x/r update and the direction update / its bookkeeping.  In the lean form
+ * (mfs_pcg3d_set_lean) the bookkeeping of iteration j is done by the stencil launch of j + 1, or -- when a poll, history,
+ * finish or another loop form comes first -- by a one-block launch those calls enqueue themselves. */
 int mfs_pcg3d_native_apply(mfs_pcg3d* h, mfs_stream stream);
 int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream);
 /* after mfs_pcg3d_iterate calls of one's own: settle what the fused loop forms still owe -- the deferred x update

@@ -191,6 +191,7 @@ struct mfs_pcg3d {
   size_t ws_bytes;
   void *diag, *cx, *cy, *cz;
   bool x_owed;                 // the loop has deferred an x update that pcg_home_d still has to apply
+  bool book_pending;           // lean loop: the last enqueued iteration's bookkeeping has not been launched yet
   bool slab_loop;              // the running solve is the slab loop (x lives on the owned planes [1, Nx-1) only)
   int defer_x;                 // 1: native fused loop lets x += alpha d ride in the NEXT stencil launch (mfs_pcg3d_finish owes the last one)
   int jacobi;                  // 1: opt-in Jacobi-preconditioned loop (mfs_pcg3d_set_jacobi); NOT the reference's CG
@@ -395,6 +396,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->jacobi = env_int("MFS_JACOBI", 0);
   h->defer_x = env_int("MFS_DEFER_X", -1);
   h->x_owed = false;
+  h->book_pending = false;
   h->lean = env_int("MFS_LEAN", -1);
   h->slab_loop = false;
   h->fuse = env_int("MFS_FUSE_D", 1);
@@ -604,6 +606,7 @@ int mfs_pcg3d_phase_update_d(mfs_pcg3d* h, mfs_stream stream) {
 int mfs_pcg3d_begin_local(mfs_pcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   h->x_owed = false;
+  h->book_pending = false;
   h->slab_loop = false;
   hipStream_t st = (hipStream_t)stream;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
@@ -683,28 +686,51 @@ static bool native_fuse_ok(const mfs_pcg3d* h) {
   return h->fuse != 0 && !h->jacobi && h->variant == 2 && vec_in && h->Ny >= 3 && h->Nz >= 3 && h->Nx >= 3;
 }
 
+// the tail-less form of the fused loop (see BookArgs)
+static bool lean_ok(const mfs_pcg3d* h) {
+  return h->lean != 0 && native_fuse_ok(h) && h->pd < 2;
+}
+
+// The lean loop leaves iteration j open (its r.r partials written, its bookkeeping not) until the stencil launch of
+// j + 1 closes it.  Whoever needs the scalar block complete -- a poll, the end of a batch, a switch of loop form --
+// closes it with the one-block bookkeeping launch instead.
+static int pcg_close_pending(mfs_pcg3d* h, hipStream_t st) {
+  if (!h->book_pending) return MFS_OK;
+  h->book_pending = false;
+  hipLaunchKernelGGL(k_cg_book, dim3(1), dim3(kBlock), 0, st, h->c.scal, h->c.hist, kHistCap,
+                     (int)((h->c.iter_enq - 1) & 1), h->c.part_rr, h->c.n_part_rr);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
 // the stencil launch of native iteration j = iter_enq: plain for j = 0, else with d_j = r + beta d_{j-1}
-// formed on the fly into the other buffer of the pair {bound d, d2} (beta from k_cg_book of j-1)
+// formed on the fly into the other buffer of the pair {bound d, d2}; beta from the scalar block, or -- lean loop, iteration
+// j - 1 still open -- from the r.r partials, the launch closing j - 1 itself (BookArgs)
 int mfs_pcg3d_native_apply(mfs_pcg3d* h, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
+  int e;
+  if (!lean_ok(h) && (e = pcg_close_pending(h, st))) return e;
   if (!native_fuse_ok(h)) return mfs_pcg3d_phase_apply(h, 1, h->Nx - 1, 1, stream);
   const int64_t j = h->c.iter_enq;
   void* d_cur = (j & 1) ? h->d2 : h->c.d;
   void* d_prev = (j & 1) ? h->c.d : h->d2;
-  int grid = 0, e;
+  int grid = 0;
   if (j == 0) {
     if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid))) return e;
   } else {
     FuseArgs fz{h->c.r, d_prev, d_cur};
     if (xdef_ok(h)) fz.xdef = h->c.x;
+    fz.book = h->book_pending;
+    h->book_pending = false;
     if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e;
   }
   h->c.n_part_dq = grid;
   return MFS_OK;
 }
 
-// the rest of native iteration j: x/r update (d.q folded in) and the direction update or its bookkeeping
+// the rest of native iteration j: x/r update (d.q folded in) and -- unless the lean loop leaves that to the next
+// stencil launch -- the direction update or its bookkeeping
 int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
@@ -714,51 +740,35 @@ int mfs_pcg3d_native_finish(mfs_pcg3d* h, mfs_stream stream) {
     return core_update_d(h->c, true, st);
   }
   const int64_t j = h->c.iter_enq;
+  void* d_cur = (j & 1) ? h->d2 : h->c.d;
+  const bool xdef = xdef_ok(h);
+  if (xdef) h->x_owed = true;                    // r only: x += alpha d rides in the next stencil launch
+  if (lean_ok(h)) {
+    if ((e = core_update_xr(h->c, true, st, xdef ? 1 : 0, d_cur))) return e;
+    ++h->c.iter_enq;
+    h->book_pending = true;
+    return MFS_OK;
+  }
   // the last block of the update closes the iteration (convergence test, history, beta): 2 launches per iteration
-  if (xdef_ok(h)) {   // r only: x += alpha d rides in the next stencil launch
-    h->x_owed = true;
+  if (xdef) {
     XrTail tl{1, h->c.hist, kHistCap, nullptr, 0, 0};
-    if ((e = core_update_xr(h->c, true, st, 1, (j & 1) ? h->d2 : h->c.d, 0, -1, &tl, nullptr))) return e;
+    if ((e = core_update_xr(h->c, true, st, 1, d_cur, 0, -1, &tl, nullptr))) return e;
     ++h->c.iter_enq;
     return MFS_OK;
   }
-  return core_update_xr_close(h->c, true, st, (j & 1) ? h->d2 : h->c.d, 1);
+  return core_update_xr_close(h->c, true, st, d_cur, 1);
 }
 
-// the tail-less form of the fused loop (see BookArgs)
-static bool lean_ok(const mfs_pcg3d* h) {
-  return h->lean != 0 && native_fuse_ok(h) && h->pd < 2;
-}
-
-// n iterations as  A_0 U | A*_1 U | ... | A*_{n-1} U | B : A plain fused stencil launch (beta from the scalar block),
-// A* = stencil launch that first closes the iteration before it, U = x/r update without a tail, B = one-block
-// bookkeeping for the last iteration of the batch -- so that the scalar block is complete whenever the host looks.
+// n iterations as  A U | A* U | ... | A* U | B : A = fused stencil launch (beta from the scalar block), A* = stencil launch
+// that first closes the iteration before it, U = x/r update without a tail, B = one-block bookkeeping for the last
+// iteration of the batch -- so that the scalar block is complete whenever the host looks.
 static int pcg_iterate_lean(mfs_pcg3d* h, int64_t n, hipStream_t st) {
-  const bool xdef = xdef_ok(h);
   for (int64_t i = 0; i < n; ++i) {
-    const int64_t j = h->c.iter_enq;
-    void* d_cur = (j & 1) ? h->d2 : h->c.d;
-    void* d_prev = (j & 1) ? h->c.d : h->d2;
-    int grid = 0, e;
-    if (j == 0) {
-      if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid))) return e;
-    } else {
-      FuseArgs fz{h->c.r, d_prev, d_cur};
-      fz.book = i > 0;
-      if (xdef) fz.xdef = h->c.x;
-      if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e;
-    }
-    h->c.n_part_dq = grid;
-    if (xdef) h->x_owed = true;                  // r only: x += alpha d rides in the next stencil launch
-    if ((e = core_update_xr(h->c, true, st, xdef ? 1 : 0, d_cur))) return e;
-    ++h->c.iter_enq;
+    int e;
+    if ((e = mfs_pcg3d_native_apply(h, (mfs_stream)st))) return e;
+    if ((e = mfs_pcg3d_native_finish(h, (mfs_stream)st))) return e;
   }
-  if (n > 0) {
-    hipLaunchKernelGGL(k_cg_book, dim3(1), dim3(kBlock), 0, st, h->c.scal, h->c.hist, kHistCap,
-                       (int)((h->c.iter_enq - 1) & 1), h->c.part_rr, h->c.n_part_rr);
-    MFS_LAUNCH_CHECK();
-  }
-  return MFS_OK;
+  return pcg_close_pending(h, st);
 }
 
 // the resident loop (mfs_pcg_resident.h): a grid that fits W workgroups' registers, the fused loop's preconditions
@@ -821,6 +831,8 @@ static int pcg_iterate_resident(mfs_pcg3d* h, int64_t n, hipStream_t st) {
 
 int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
+  if (h->jacobi || resident_ok(h) || !lean_ok(h))
+    if (int e = pcg_close_pending(h, (hipStream_t)stream)) return e;
   if (!h->jacobi && resident_ok(h)) return pcg_iterate_resident(h, n, (hipStream_t)stream);
   if (!h->jacobi && lean_ok(h)) return pcg_iterate_lean(h, n, (hipStream_t)stream);
   if (h->jacobi) {
@@ -875,6 +887,7 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
                    double* beta) {
   MFS_REQUIRE(h, "null handle");
   hipStream_t st = (hipStream_t)stream;
+  if (int e = pcg_close_pending(h, st)) return e;
   // The resident loop did not get its workgroups together (a shared GPU): that launch -- and every launch queued behind
   // it -- wrote nothing, so the state is the one the scalar block describes.  Clear the flag, switch this engine to the
   // launch-per-phase loop for good, and report the iterations that did complete: the caller (mfs_pcg3d_solve does) goes on
@@ -932,6 +945,7 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
 
 int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_stream stream) {
   if (!h) { set_error("mfs_pcg3d_history: null handle"); return MFS_E_INVALID; }
+  if (int e = pcg_close_pending(h, (hipStream_t)stream)) return e;
   return core_history(h->c, out_host, cap, (hipStream_t)stream);
 }
 
@@ -1062,6 +1076,7 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(slab_ok(h), "slab loop needs an attached window, the vector path (Nz % 4 (fp32) / 2 (fp64) == 0, 16-byte aligned CG vectors) and stencil variant 2");
   hipStream_t st = (hipStream_t)stream;
   h->x_owed = false;
+  h->book_pending = false;
   h->slab_loop = true;
   ++h->p2p->epoch;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
