@@ -309,7 +309,19 @@ int mfs_vcg3d_apply(mfs_vcg3d* h, const void* v, void* out, mfs_stream stream);
 int mfs_vcg3d_bind(mfs_vcg3d* h, void* b, void* x, void* d, void* r, void* q);
 /* q=A x (x = extrapolated velocity, NOT zeroed); d=r=b-q; delta0   (:575-587) */
 int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream);
+/* n iterations of the loop :588-610: stencil launch, r update, direction + x update.  Opt-in form (mfs_vcg3d_set_fuse,
+ * where the x-marching kernel serves the engine -- mfs_vcg3d_loop_info bit 0): 2 launches per iteration -- the stencil launch of iteration j also forms d_j = r + beta d_{j-1} (:609-610) and
+ * performs x += alpha d_{j-1} (:595-597) for the faces it owns, the r update's last block closes the iteration (:604-608).
+ * x then lags one update behind and d_j may sit in an engine buffer until mfs_vcg3d_finish / the end of mfs_vcg3d_solve. */
 int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream);
+/* settles what mfs_vcg3d_iterate's fused loop owes (last x update; d_iters = r + beta d unless converged, brought home to
+ * the bound `d`): state as after the reference's loop :588-610.  Host-synchronous; begin again before iterating further. */
+int mfs_vcg3d_finish(mfs_vcg3d* h, mfs_stream stream);
+/* 1 / 0: fused direction + x update in mfs_vcg3d_iterate / solve (default 0 -- measured slower, DESIGN.md section 4;
+ * env MFS_VISC_FUSE); results bit-identical */
+int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on);
+/* bit 0: mfs_vcg3d_iterate will run the fused 2-launch loop for the engine as bound and set up */
+int mfs_vcg3d_loop_info(mfs_vcg3d* h);
 int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);
 int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every,

@@ -37,6 +37,10 @@
 #define MFS_VMARCH_MIN_WAVES 2     // waves per SIMD the kernel is compiled for (256 VGPRs)
 #endif
 
+#ifndef MFS_VM_FUSE_TOP
+#define MFS_VM_FUSE_TOP 0       // FUSE: 1 = all three components of plane x+2 requested at the top of the step, 0 = one per phase
+#endif
+
 #ifndef MFS_VM_CELL_GROUP
 #define MFS_VM_CELL_GROUP 0     // cells of a vector whose accumulation chains are interleaved (0: all of them)
 #endif
@@ -295,22 +299,47 @@ __host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing 
 #define MFS_VM_NBR(off) (off)
 #endif
 
+// FUSE (the fused loop of mfs_vcg3d_iterate, iteration j >= 1): the launch also performs the two vector updates the
+// reference does between two applies (ViscosityCGSolver3D.py:595-597, :609-610) for every face it owns --
+//     x += alpha_{j-1} d_{j-1} ;  d_j = r_j + beta_{j-1} d_{j-1} ;  q = A d_j
+// `v` is then d_{j-1} (read only), d_j goes to the OTHER buffer of the pair {bound d, engine buffer} (fz.dn: neighbouring
+// workgroups and the slab blocks still read d_{j-1}), and every operand of the operator -- own vectors, halo rows, the
+// x-1 / x+1 planes of a march, the slab rows' taps -- is formed on the fly as (T)(r + beta d_{j-1}): the arithmetic of
+// k_update_d, rounded to the storage type like the stored d_j, so q is bit-identical to the three-kernel loop.  A face
+// is WRITTEN (d_j, x) by exactly one owner: planes [x0, x1) of a march's tile, the cells q is stored for.
+// 13 + 12 scalars per cell instead of 13 + 15 in two launches, and one dependent launch less per iteration.
+template <typename T>
+struct VmFuse {
+  const T* r[3];          // residual components (read)
+  T* dn[3];               // d_j (written once per owned face)
+  T* x[3];                // solution (read-modify-write by the owner)
+  const double* scal;     // S_ALPHA / S_BETA of the iteration closed by the previous launch
+};
+
 // slabs: the three boundary slabs (u at x = Nx-1, v at y = Ny-1, w at z = Nz-1) ride as extra blocks, as in k_vcg_apply_all
-template <typename T, int VEC, int WAVES, int NT>
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false>
 __global__ void __launch_bounds__(kVmBlock, WAVES)
 k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
                   int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
-                  const double* __restrict__ done_flag) {
+                  const double* __restrict__ done_flag, VmFuse<T> fz) {
   // the flag is REQUESTED here and tested where the first march's own loads have been issued: on a small grid the
   // launch is a chain of memory round trips, and flag -> planes was two of them (loads past a raised flag are harmless)
   const double dn = done_flag ? *done_flag : 0.0;
+  const double f_alpha = FUSE ? fz.scal[S_ALPHA] : 0.0, f_beta = FUSE ? fz.scal[S_BETA] : 0.0;
   double acc = 0.0;
   if ((int)blockIdx.x >= gmain) {
     if (dn != 0.0) return;
     const int b = (int)blockIdx.x - gmain, g2 = (int)gridDim.x - gmain - g0 - g1;
-    if (b < g0) acc = vcg_slab_rows<T, 0, false>(c, k1, k2, v, ox, b0, b, g0);
-    else if (b < g0 + g1) acc = vcg_slab_rows<T, 1, false>(c, k1, k2, v, oy, b1, b - g0, g1);
-    else acc = vcg_slab_rows<T, 2, false>(c, k1, k2, v, oz, b2, b - g0 - g1, g2);
+    if constexpr (FUSE) {
+      const Vec3T<T> rr{{fz.r[0], fz.r[1], fz.r[2]}};
+      if (b < g0) acc = vcg_slab_rows_fused<T, 0>(c, k1, k2, v, rr, f_alpha, f_beta, ox, fz.dn[0], fz.x[0], b0, b, g0);
+      else if (b < g0 + g1) acc = vcg_slab_rows_fused<T, 1>(c, k1, k2, v, rr, f_alpha, f_beta, oy, fz.dn[1], fz.x[1], b1, b - g0, g1);
+      else acc = vcg_slab_rows_fused<T, 2>(c, k1, k2, v, rr, f_alpha, f_beta, oz, fz.dn[2], fz.x[2], b2, b - g0 - g1, g2);
+    } else {
+      if (b < g0) acc = vcg_slab_rows<T, 0, false>(c, k1, k2, v, ox, b0, b, g0);
+      else if (b < g0 + g1) acc = vcg_slab_rows<T, 1, false>(c, k1, k2, v, oy, b1, b - g0, g1);
+      else acc = vcg_slab_rows<T, 2, false>(c, k1, k2, v, oz, b2, b - g0 - g1, g2);
+    }
     const double tot = block_sum<kVmBlock>(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
     return;
@@ -399,6 +428,50 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       if (hact) { vstore<T, VEC>(b + hl, p.hu); vstore<T, VEC>(b + SU + hl, p.hv); vstore<T, VEC>(b + 2 * SU + hl, p.hw); }
     };
 
+    // FUSE: one component of one plane -- d_{j-1} and r of the own vector and of the halo vector, x of the own vector --
+    // requested (fload), and later turned into d_j for the plane's image, and, on a plane this march owns, into the
+    // stored d_j and the updated x (fform).  Component by component, so that 5 vectors are in flight at a time.
+    struct CompLd { V d, hd, r, hr, x; };
+    auto fload = [&](int comp, int xp, bool owned) {
+      CompLd l;
+      l.hd = V{}; l.hr = V{}; l.x = V{};
+      if constexpr (FUSE) {
+        const int64_t ps = comp == 0 ? su : (comp == 1 ? sv : sw);
+        const int64_t oo = (int64_t)xp * ps + (comp == 2 ? o_w : o_uv), oh = (int64_t)xp * ps + (comp == 2 ? hgw : hg);
+        if (comp < 2) {
+          l.d = vload<T, VEC>(v.p[comp] + oo); l.r = vload<T, VEC>(fz.r[comp] + oo);
+          if (hact) { l.hd = vload<T, VEC>(v.p[comp] + oh); l.hr = vload<T, VEC>(fz.r[comp] + oh); }
+          if (owned) l.x = (NT & 4) ? vload_nt<T, VEC>(fz.x[comp] + oo) : vload<T, VEC>(fz.x[comp] + oo);
+        } else {
+          l.d = vload_u<T, VEC>(v.p[comp] + oo); l.r = vload_u<T, VEC>(fz.r[comp] + oo);
+          if (hact) { l.hd = vload_u<T, VEC>(v.p[comp] + oh); l.hr = vload_u<T, VEC>(fz.r[comp] + oh); }
+          if (owned) l.x = vload_u<T, VEC>(fz.x[comp] + oo);
+        }
+      } else {
+        l.d = V{}; l.r = V{};
+      }
+      return l;
+    };
+    auto fform = [&](int comp, int xp, bool owned, const CompLd& l, T* slot) {
+      if constexpr (FUSE) {
+        V dj, hj, xn;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          dj[j] = (T)__builtin_fma(f_beta, (double)l.d[j], (double)l.r[j]);
+          hj[j] = (T)__builtin_fma(f_beta, (double)l.hd[j], (double)l.hr[j]);
+          xn[j] = (T)__builtin_fma(f_alpha, (double)l.d[j], (double)l.x[j]);
+        }
+        if (active) vstore<T, VEC>(slot + comp * SU + lu, dj);
+        if (hact) vstore<T, VEC>(slot + comp * SU + hl, hj);
+        if (owned && active) {
+          const int64_t ps = comp == 0 ? su : (comp == 1 ? sv : sw);
+          const int64_t oo = (int64_t)xp * ps + (comp == 2 ? o_w : o_uv);
+          if (comp < 2) { vm_store<T, VEC, true, 0>(fz.dn[comp] + oo, dj, first, last); vm_store<T, VEC, true, NT>(fz.x[comp] + oo, xn, first, last); }
+          else { vm_store<T, VEC, false, 0>(fz.dn[comp] + oo, dj, first, last); vm_store<T, VEC, false, 0>(fz.x[comp] + oo, xn, first, last); }
+        }
+      }
+    };
+
     // z neighbours by DPP.  Lane l-1 / l+1 of the wave holds the row's previous / next vector whenever this lane's
     // vector is not the first / last of its row (then the neighbour is never used); only lane 0 / 63 can have its
     // neighbour in another wave, and only when a wave's 64 vectors do not start on a row boundary, i.e. 64 % nzv != 0:
@@ -411,9 +484,22 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     VmRegs<T, VEC> rg;
     // ---- prologue: the images of planes x0-1, x0, x0+1 into ring slots 0, 1, 2; the volume samples of the first step
     {
-      const Plane pa = fetch(x0 - 1), pb = fetch(x0), pc = fetch(x0 + 1);
-      if (dn != 0.0) return;                                   // uniform over the grid
-      publish(smem, pa); publish(smem + BUF, pb); publish(smem + 2 * BUF, pc);
+      if constexpr (FUSE) {
+        // all nine component loads of the three planes in one batch, then formed into the ring (and, for the planes this
+        // march owns, into d_j and x)
+        const bool ob = true, oc = x0 + 1 < x1;
+        const CompLd a0 = fload(0, x0 - 1, false), a1 = fload(1, x0 - 1, false), a2 = fload(2, x0 - 1, false);
+        const CompLd b0_ = fload(0, x0, ob), b1_ = fload(1, x0, ob), b2_ = fload(2, x0, ob);
+        const CompLd c0 = fload(0, x0 + 1, oc), c1 = fload(1, x0 + 1, oc), c2 = fload(2, x0 + 1, oc);
+        if (dn != 0.0) return;                                 // uniform over the grid
+        fform(0, x0 - 1, false, a0, smem); fform(1, x0 - 1, false, a1, smem); fform(2, x0 - 1, false, a2, smem);
+        fform(0, x0, ob, b0_, smem + BUF); fform(1, x0, ob, b1_, smem + BUF); fform(2, x0, ob, b2_, smem + BUF);
+        fform(0, x0 + 1, oc, c0, smem + 2 * BUF); fform(1, x0 + 1, oc, c1, smem + 2 * BUF); fform(2, x0 + 1, oc, c2, smem + 2 * BUF);
+      } else {
+        const Plane pa = fetch(x0 - 1), pb = fetch(x0), pc = fetch(x0 + 1);
+        if (dn != 0.0) return;                                   // uniform over the grid
+        publish(smem, pa); publish(smem + BUF, pb); publish(smem + 2 * BUF, pc);
+      }
       const T* const q = C1 + (int64_t)x0 * sc + o_c;          // class 1 of this vector; class p at q + (p-1)*cs
       rg.cm = vload<T, VEC>(q + 6 * cs - sc);
       rg.exyc = vload<T, VEC>(q); rg.exzc = vload<T, VEC>(q + cs);
@@ -443,7 +529,16 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       // (the last two steps of a march need no further plane, its last step no further class samples: wave-uniform skips)
       const bool need_plane = x + 2 <= x1, more = x + 1 < x1;
       Plane pn = Plane{};
-      if (need_plane) pn = fetch(x + 2);
+      const bool own_n = x + 2 < x1;                              // FUSE: plane x+2 is one of this march's own
+      CompLd fl = CompLd{}, fl1 = CompLd{}, fl2 = CompLd{};
+      if (need_plane) {
+        if constexpr (FUSE) {
+          fl = fload(0, x + 2, own_n);
+          if (MFS_VM_FUSE_TOP) { fl1 = fload(1, x + 2, own_n); fl2 = fload(2, x + 2, own_n); }
+        } else {
+          pn = fetch(x + 2);
+        }
+      }
       const T* const qn = C1 + (int64_t)min(x + 1, Nx - 2) * sc + o_c;      // next step's class samples
       const unsigned char* const mqn = MP + (int64_t)min(x + 1, Nx - 2) * sc + o_c;
       MFS_VM_PIN();
@@ -471,6 +566,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
         fxn = MFS_VM_LD1(qn + 2 * cs); ccn = MFS_VM_LD2(qn + 6 * cs); exyypn = vload<T, VEC>(qn + MFS_VM_NBR(c.pz));
         if (fixr) exzzrn = qn[cs + VEC];
       }
+      if constexpr (FUSE) if (need_plane) { fform(0, x + 2, own_n, fl, bw); if (!MFS_VM_FUSE_TOP) fl1 = fload(1, x + 2, own_n); }
       MFS_VM_PIN();
       MFS_VM_STAMP(5);                                           // u: store + issue of the next step's samples
       // ---- (4) v rows
@@ -501,6 +597,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
         if (fixr) eyzzrn = qn[3 * cs + VEC];
         mskn = MFS_VM_MK(vm_mask<VEC>(mqn));
       }
+      if constexpr (FUSE) if (need_plane) { fform(1, x + 2, own_n, fl1, bw); if (!MFS_VM_FUSE_TOP) fl2 = fload(2, x + 2, own_n); }
       MFS_VM_PIN();
       MFS_VM_STAMP(8);                                           // v: store + issue
       // ---- (5) w rows
@@ -532,7 +629,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       }
       MFS_VM_PIN();
       // ---- (6) plane x+2 into its slot (its loads have had the whole step); next step's class samples take over
-      if (need_plane) publish(bw, pn);
+      if (need_plane) { if constexpr (FUSE) fform(2, x + 2, own_n, fl2, bw); else publish(bw, pn); }
       MFS_VM_STAMP(11);                                          // w: store + issue, publish of plane x+2 (waits for its loads)
       rg.cm = rg.cc; rg.cc = ccn;
       rg.exyc = rg.exyp; rg.exyp = exypn; rg.exzc = rg.exzp; rg.exzp = exzpn;

@@ -425,6 +425,55 @@ __device__ __forceinline__ double vcg_slab_rows(const Compact& c, double k1, dou
   return acc;
 }
 
+// The slab rows of the FUSED loop (mfs_vcg_march.h, FUSE): every operand is d_j = (T)(r + beta d_{j-1}) formed on the
+// fly from the two arrays (the stored d_j belongs to other blocks of the same launch), the row's own face gets its d_j
+// stored and its x updated -- k_update_d's arithmetic, face by face.
+template <typename T>
+struct FusedSampler {
+  const Compact& c;
+  const Vec3T<T>& dp;      // d_{j-1}
+  const Vec3T<T>& r;
+  double beta;
+  int x, y, z;
+  __device__ __forceinline__ double vol(int p, int ox, int oy, int oz) const {
+    return (double)((const T*)c.vol[p])[c.idx(x + ox, y + oy, z + oz)];
+  }
+  __device__ __forceinline__ int64_t fidx(int comp, int dx, int dy, int dz) const {
+    const int cs1 = c.N[1] + (comp == 1), cs2 = c.N[2] + (comp == 2);
+    return ((int64_t)(x + dx) * cs1 + (y + dy)) * cs2 + (z + dz);
+  }
+  __device__ __forceinline__ double vel(int comp, int dx, int dy, int dz) const {
+    const int64_t i = fidx(comp, dx, dy, dz);
+    return (double)(T)__builtin_fma(beta, (double)dp.p[comp][i], (double)r.p[comp][i]);
+  }
+  __device__ __forceinline__ bool tap_ok(int, int, int, int) const { return true; }
+};
+
+template <typename T, int AXIS>
+__device__ __forceinline__ double vcg_slab_rows_fused(const Compact& c, double k1, double k2, const Vec3T<T>& dp,
+                                                      const Vec3T<T>& r, double alpha, double beta, T* __restrict__ out,
+                                                      T* __restrict__ dn, T* __restrict__ xs, const Box3& bx, int blk, int nblk) {
+  const int s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
+  const int i0 = bx.hi[0] - bx.lo[0], i1 = bx.hi[1] - bx.lo[1], i2 = bx.hi[2] - bx.lo[2];
+  const int64_t nint = (int64_t)i0 * i1 * i2;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
+  double acc = 0.0;
+  for (int64_t it = (int64_t)blk * blockDim.x + threadIdx.x; it < nint; it += stride) {
+    const int z = bx.lo[2] + (int)(it % i2), y = bx.lo[1] + (int)((it / i2) % i1), x = bx.lo[0] + (int)(it / ((int64_t)i2 * i1));
+    const FusedSampler<T> smp{c, dp, r, beta, x, y, z};
+    const bool own_ok = ((c.msk[c.idx(x, y, z)] >> AXIS) & 1) != 0;
+    double own;
+    const double val = vcg_row_s<AXIS, false>(smp, k1, k2, own_ok, own);
+    const T o = (T)val;
+    const int64_t i = ((int64_t)x * s1 + y) * s2 + z;
+    out[i] = o;
+    dn[i] = (T)own;
+    xs[i] = (T)__builtin_fma(alpha, (double)dp.p[AXIS][i], (double)xs[i]);
+    acc += own * (double)o;
+  }
+  return acc;
+}
+
 template <typename T, bool MASK>
 __global__ void __launch_bounds__(256)
 k_vcg_apply_slabs(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
@@ -691,6 +740,9 @@ struct mfs_vcg3d {
   int march_bpc;   // its workgroups per CU (2: what its register budget makes resident)
   int march_vec;   // experiment: 2 = 8-byte vectors for fp32 state
   mfs_p2p* p2p;    // window transport of the slab loop (mfs_vcg3d_attach_p2p); null: the caller moves halos / scalars
+  int fuse;        // 1: mfs_vcg3d_iterate / solve fold the direction and x updates into the march (2 launches per iteration); default 0
+  void* d2;        // ping-pong partner of the bound d for that loop (n elements, zero outside the faces the loop writes)
+  bool fused_run;  // the fused loop has run since begin: x lags by one update, d_j may sit in d2 (vcg_home settles both)
 };
 
 // elements one class / mask array occupies (uniform pitches, see struct Compact)
@@ -765,9 +817,9 @@ static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
   return true;
 }
 
-template <typename T, int VEC, int WAVES, int NT>
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false>
 static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
-                               int* nparts) {
+                               int* nparts, const VmFuse<T>* fz = nullptr) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + kVmBlock - 1) / kVmBlock;
   const int64_t total = (int64_t)tiles * (Nx - 2);
@@ -778,12 +830,13 @@ static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* 
   const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
   static bool attr_set = false;        // per instantiation: more than the default 64 KB of dynamic LDS
   if (!attr_set) {
-    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kVmMaxLds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
-                     h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial, done);
+  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT, FUSE>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
+                     h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial, done,
+                     fz ? *fz : VmFuse<T>{});
   MFS_LAUNCH_CHECK();
   *nparts = gmain + g0 + g1 + g2;
   return MFS_OK;
@@ -798,6 +851,25 @@ static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* par
   const bool nt = knob < 0 ? (13.0 * (double)h->g.N[0] * h->g.N[1] * h->g.N[2] * sizeof(T) > 200e6) : (knob != 0);
   return nt ? vcg_march_launch_nt<T, VEC, WAVES, 5>(h, vv, ob, partial, done, st, nparts)
             : vcg_march_launch_nt<T, VEC, WAVES, 0>(h, vv, ob, partial, done, st, nparts);
+}
+
+// the stencil launch of fused iteration j >= 1: q = A d_j with d_j = r + beta d_{j-1} formed on the fly and stored to
+// `d_cur`, x += alpha d_{j-1} for every owned face (mfs_vcg_march.h, FUSE)
+template <typename T>
+static int vcg_march_fused(mfs_vcg3d* h, const void* d_prev, void* d_cur, hipStream_t st, int* nparts) {
+  constexpr int VEC = VecOf<T>::N;
+  const T* dp = (const T*)d_prev;
+  T* dc = (T*)d_cur;
+  T* xb = (T*)h->c.x;
+  const T* rb = (const T*)h->c.r;
+  Vec3T<T> vv{{dp + h->off[0], dp + h->off[1], dp + h->off[2]}};
+  VmFuse<T> fz;
+  for (int a = 0; a < 3; ++a) { fz.r[a] = rb + h->off[a]; fz.dn[a] = dc + h->off[a]; fz.x[a] = xb + h->off[a]; }
+  fz.scal = h->c.scal;
+  const int knob = env_int("MFS_VISC_MARCH_NT", -1);
+  const bool nt = knob < 0 ? (13.0 * (double)h->g.N[0] * h->g.N[1] * h->g.N[2] * sizeof(T) > 200e6) : (knob != 0);
+  return nt ? vcg_march_launch_nt<T, VEC, MFS_VMARCH_MIN_WAVES, 5, true>(h, vv, (T*)h->c.q, h->c.part_dq, h->c.scal + S_DONE, st, nparts, &fz)
+            : vcg_march_launch_nt<T, VEC, MFS_VMARCH_MIN_WAVES, 0, true>(h, vv, (T*)h->c.q, h->c.part_dq, h->c.scal + S_DONE, st, nparts, &fz);
 }
 
 template <typename T, bool MASK>
@@ -1160,6 +1232,7 @@ size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   size_t tot = core_ws_bytes() + 4096;
   for (int p = 1; p < 8; ++p) tot += class_stride_bytes(gres, dt);
   tot += align_up((size_t)class_count(gres, 0), 4096);       // the packed mask bytes
+  tot += align_up((size_t)mfs_vcg3d_dofs(gres) * dtype_size(dt), 4096);   // partner of d (fused loop)
   return tot;
 }
 
@@ -1191,6 +1264,9 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->cp.vol[0] = nullptr;
   for (int q = 1; q < 8; ++q) { h->cp.vol[q] = p; p += class_stride_bytes(gres, dt); }
   h->cp.msk = (unsigned char*)p; p += align_up((size_t)class_count(gres, 0), 4096);
+  h->d2 = p; p += align_up((size_t)h->n * dtype_size(dt), 4096);
+  h->fuse = env_int("MFS_VISC_FUSE", 0);   // measured slower than the three-launch loop: opt-in
+  h->fused_run = false;
   h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
   h->is_setup = false;
   h->mask_cg = env_int("MFS_VISC_MASK_CG", 0);
@@ -1273,6 +1349,7 @@ int mfs_vcg3d_bind(mfs_vcg3d* h, void* b, void* x, void* d, void* r, void* q) {
 int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
+  h->fused_run = false;
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;     // x keeps the extrapolated velocity (:569-573)
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;   // :575
@@ -1295,6 +1372,7 @@ void* mfs_vcg3d_scalars(mfs_vcg3d* h) { return h ? h->c.scal : nullptr; }
 int mfs_vcg3d_begin_local(mfs_vcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
+  h->fused_run = false;
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
@@ -1348,6 +1426,7 @@ int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup && h->p2p, "engine not bound / set up / no window attached");
   ++h->p2p->epoch;
   hipStream_t st = (hipStream_t)stream;
+  h->fused_run = false;
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
@@ -1365,9 +1444,39 @@ int mfs_vcg3d_slab_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   return MFS_OK;
 }
 
+// can the fused loop serve the engine as bound?  (the marching kernel's preconditions, 16-byte aligned CG vectors)
+static bool vcg_fuse_ok(const mfs_vcg3d* h) {
+  if (!h->fuse || !h->split_x || h->mask_cg || h->tiled || h->march_vec == 2 || !h->c.d || !core_vec_ok(h->c)) return false;
+  return h->dt == MFS_F32 ? vcg_march_ok<float>(h, h->c.d, h->c.q) : vcg_march_ok<double>(h, h->c.d, h->c.q);
+}
+
 int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
+  if (vcg_fuse_ok(h)) {
+    // Fused loop, 2 launches per iteration:  A | R   A* | R   A* | R ...   A = plain march (iteration 0: d_0 = r_0 is there),
+    // A* = march that first forms d_j = r + beta d_{j-1} (into the other buffer of {bound d, d2}) and lets x += alpha d_{j-1}
+    // ride along, R = r -= alpha q whose last block closes the iteration (test :606, history, alpha, beta).  x lags one
+    // update behind and d_j may sit in d2 until vcg_home (mfs_vcg3d_finish / the end of mfs_vcg3d_solve) settles both.
+    for (int64_t i = 0; i < n; ++i) {
+      int e, np = 0;
+      const int64_t j = h->c.iter_enq;
+      void* d_cur = (j & 1) ? h->d2 : h->c.d;
+      void* d_prev = (j & 1) ? h->c.d : h->d2;
+      if (j == 0) {
+        if ((e = vcg_apply(h, d_cur, h->c.q, h->c.part_dq, true, false, st, &np))) return e;                    // :589
+      } else {
+        e = h->dt == MFS_F32 ? vcg_march_fused<float>(h, d_prev, d_cur, st, &np) : vcg_march_fused<double>(h, d_prev, d_cur, st, &np);
+        if (e) return e;                                                                                          // :595-597 (x), :609-610, :589
+      }
+      h->c.n_part_dq = np;
+      h->fused_run = true;
+      XrTail tl{1, h->c.hist, kHistCap, nullptr, 0, 0};
+      if ((e = core_update_xr(h->c, true, st, 1, d_cur, 0, -1, &tl, nullptr))) return e;                          // :592-601 (r), :604-608
+      ++h->c.iter_enq;
+    }
+    return MFS_OK;
+  }
   for (int64_t i = 0; i < n; ++i) {
     int e, np = 0;
     if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;   // :589
@@ -1380,6 +1489,27 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
       if ((e = core_update_d(h->c, true, st))) return e;                              // :604-610
     }
   }
+  return MFS_OK;
+}
+
+// what the fused loop owes when it stops after `iters` completed iterations: x += alpha d of the last one, the direction
+// update d_iters = r + beta d_{iters-1} unless it converged (the reference updates d at the end of every non-converged
+// iteration, :609-610), and d brought home to the bound array if it sits in the partner buffer
+static int vcg_home(mfs_vcg3d* h, int64_t iters, bool converged, hipStream_t st) {
+  if (!h->fused_run) return MFS_OK;
+  h->fused_run = false;
+  if (iters < 1) return MFS_OK;
+  void* cur = ((iters - 1) & 1) ? h->d2 : h->c.d;             // holds d_{iters-1}
+  const int grid = core_vec_grid(h->c, true);
+  if (h->dt == MFS_F32) hipLaunchKernelGGL((k_x_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.x, (const float*)cur, h->n, h->c.scal);
+  else hipLaunchKernelGGL((k_x_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.x, (const double*)cur, h->n, h->c.scal);
+  MFS_LAUNCH_CHECK();
+  if (!converged) {
+    if (h->dt == MFS_F32) hipLaunchKernelGGL((k_d_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)h->c.r, h->n, h->c.scal);
+    else hipLaunchKernelGGL((k_d_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)h->c.r, h->n, h->c.scal);
+    MFS_LAUNCH_CHECK();
+  }
+  if (cur != h->c.d) MFS_HIP_TRY(hipMemcpyAsync(h->c.d, cur, (size_t)h->n * h->c.elt, hipMemcpyDeviceToDevice, st));
   return MFS_OK;
 }
 
@@ -1403,8 +1533,34 @@ int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_ev
     enq += n;
     if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
   }
+  if (int e = vcg_home(h, iters, done != 0, (hipStream_t)stream)) return e;
   if (iters_host) *iters_host = iters;
   return done ? MFS_OK : MFS_NOT_CONVERGED;
+}
+
+// for callers that drive begin / iterate themselves: settles what the fused loop owes (the last x update, the direction
+// vector parked in the engine's partner buffer).  Host-synchronous (it needs the iteration count); the loop must be
+// started again with mfs_vcg3d_begin afterwards.
+int mfs_vcg3d_finish(mfs_vcg3d* h, mfs_stream stream) {
+  MFS_REQUIRE(h, "null handle");
+  int64_t iters = 0;
+  int done = 0;
+  if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  return vcg_home(h, iters, done != 0, (hipStream_t)stream);
+}
+
+// 1 / 0: fold the direction and x updates into the marching kernel (default 0; MFS_VISC_FUSE)
+int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  MFS_REQUIRE(!h->fused_run, "mfs_vcg3d_set_fuse inside a fused loop: call mfs_vcg3d_finish first");
+  h->fuse = on ? 1 : 0;
+  return MFS_OK;
+}
+
+// what mfs_vcg3d_iterate will do for the engine as bound: bit 0 fused direction + x update (2 launches per iteration)
+int mfs_vcg3d_loop_info(mfs_vcg3d* h) {
+  if (!h || !h->c.x || !h->is_setup) return 0;
+  return vcg_fuse_ok(h) ? 1 : 0;
 }
 
 int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream) {

@@ -127,6 +127,9 @@ SIGNATURES = {
     "mfs_vcg3d_iterate": (_i, [_p, _i64, _p]),
     "mfs_vcg3d_poll": (_i, [_p, _p, _pi64, _pint, _pd, _pd, _pd]),
     "mfs_vcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
+    "mfs_vcg3d_finish": (_i, [_p, _p]),
+    "mfs_vcg3d_set_fuse": (_i, [_p, _i]),
+    "mfs_vcg3d_loop_info": (_i, [_p]),
     "mfs_vcg3d_history": (_i64, [_p, _pd, _i64, _p]),
     "mfs_vcg3d_apply_kernel": (_i, [_p]),
     "mfs_vcg3d_set_slab": (_i, [_p, _i]),

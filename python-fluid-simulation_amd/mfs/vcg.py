@@ -84,6 +84,17 @@ class VcgEngine:
     def iterate(self, n):
         _lib.check(self.lib.mfs_vcg3d_iterate(self.h, int(n), T.stream()), "mfs_vcg3d_iterate")
 
+    def finish(self):
+        """settle what the fused loop of `iterate` owes (last x update, d brought home); begin again before iterating on"""
+        _lib.check(self.lib.mfs_vcg3d_finish(self.h, T.stream()), "mfs_vcg3d_finish")
+
+    def set_fuse(self, on):
+        _lib.check(self.lib.mfs_vcg3d_set_fuse(self.h, int(bool(on))), "mfs_vcg3d_set_fuse")
+
+    def loop_info(self):
+        """{"fused": iterate() runs the 2-launch loop with the direction and x updates folded into the marching kernel}"""
+        return {"fused": bool(int(self.lib.mfs_vcg3d_loop_info(self.h)) & 1)}
+
     # ---- slab decomposition (mfs/dist.py:SlabVCG): the phases of one iteration
     def set_slab(self, skip_top_x):
         _lib.check(self.lib.mfs_vcg3d_set_slab(self.h, int(bool(skip_top_x))), "mfs_vcg3d_set_slab")

@@ -78,6 +78,7 @@ def test_viscosity_128_default_engine_vs_c_oracle(dt, tol):
     vol = H(s.vol) if dt == torch.float64 else s.vol.float().double().cpu().numpy()
     e.begin(0.0)
     e.iterate(iters)
+    e.finish()                                         # (a fused loop, MFS_VISC_FUSE=1, would owe the last x update)
     torch.cuda.synchronize()
     h = e.history()[: 2 * iters + 1]
     ref = CB.visc_cg(gres, scale, mu, b, x0, H(sc["sphi"]), vol, 0.0, iters, 2 * iters + 1)
