@@ -179,6 +179,82 @@ k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__
   });
 }
 
+// ---- the FUSED Jacobi loop (2 launches + a one-block bookkeeping launch per iteration): z = r / diag is STORED by the
+// r update -- which reads diag anyway for r.z -- into an engine buffer, and the stencil launch of the next iteration forms
+// d = z + beta d_old on the fly with the plain loop's fused kernel (k_pcg_apply_march FUSE, operand `r` := z), the
+// deferred x update riding along as there.  12 + 2 scalars per cell and iteration instead of 6 + 8 + 5 in three full passes.
+// XUPD: x += alpha d here (cache-resident sizes); otherwise the next stencil launch does it (XDEF).
+template <typename T, int VEC, bool XUPD>
+__global__ void __launch_bounds__(kBlock)
+k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q,
+                const T* __restrict__ diag, T* __restrict__ z, int64_t n, double* __restrict__ scal,
+                double* __restrict__ part_rr, double* __restrict__ part_rz, int par, const double* __restrict__ part_dq,
+                int npart) {
+  const double dn = scal[S_DONE];
+  const double delta = scal[S_RING + par];
+  const double dq = block_total_of(part_dq, npart);
+  if (dn != 0.0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
+  const double alpha = delta / dq;
+  double arr = 0.0, arz = 0.0;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      vec_t<T, VEC> rv = vload<T, VEC>(r + i), zv;
+      const vec_t<T, VEC> qv = vload<T, VEC>(q + i), gv = vload<T, VEC>(diag + i);
+      if (XUPD) {
+        vec_t<T, VEC> xv = vload<T, VEC>(x + i);
+        const vec_t<T, VEC> dv = vload<T, VEC>(d + i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
+        vstore<T, VEC>(x + i, xv);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
+        const double zz = jac_z((double)rv[j], (double)gv[j]);
+        zv[j] = (T)zz;
+        arr += (double)rv[j] * (double)rv[j];
+        arz += (double)rv[j] * zz;
+      }
+      vstore<T, VEC>(r + i, rv);
+      vstore<T, VEC>(z + i, zv);
+    } else {
+      if (XUPD) x[i] = (T)((double)x[i] + alpha * (double)d[i]);
+      const T rn = (T)((double)r[i] - alpha * (double)q[i]);
+      const double zz = jac_z((double)rn, (double)diag[i]);
+      r[i] = rn;
+      z[i] = (T)zz;
+      arr += (double)rn * (double)rn;
+      arz += (double)rn * zz;
+    }
+  });
+  const double t1 = block_sum<kBlock>(arr);
+  const double t2 = block_sum<kBlock>(arz);
+  if (threadIdx.x == 0) { part_rr[blockIdx.x] = t1; part_rz[blockIdx.x] = t2; }
+}
+
+// one block: closes a fused Jacobi iteration (k_jac_update_d's bookkeeping: test r.r < tol^2, history, delta <- r.z, alpha, beta)
+static __global__ void __launch_bounds__(kBlock)
+k_jac_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
+           const double* __restrict__ part_rr, const double* __restrict__ part_rz, int npart) {
+  if (scal[S_DONE] != 0.0) return;
+  const double rr = block_total_of(part_rr, npart);
+  const double rz = block_total_of(part_rz, npart);
+  if (threadIdx.x != 0) return;
+  const double delta = scal[S_RING + par], dq = scal[S_DQ];
+  const int64_t it = (int64_t)scal[S_ITERS];
+  if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+  scal[S_ITERS] = (double)(it + 1);
+  scal[S_RING + (par ^ 1)] = rz;
+  scal[S_RR] = rr;
+  scal[S_RZ] = rz;
+  scal[S_DELTA] = delta;
+  scal[S_LASTRR] = rr;
+  scal[S_ALPHA] = delta / dq;
+  if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
+  else if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rz / delta;
+}
+
 }  // namespace mfs
 
 using namespace mfs;
@@ -196,6 +272,7 @@ struct mfs_pcg3d {
   int defer_x;                 // 1: native fused loop lets x += alpha d ride in the NEXT stencil launch (mfs_pcg3d_finish owes the last one)
   int jacobi;                  // 1: opt-in Jacobi-preconditioned loop (mfs_pcg3d_set_jacobi); NOT the reference's CG
   double* part_rz;             // partial sums of r.z (Jacobi loop)
+  void* zb;                    // z = r / diag as stored by the fused Jacobi loop's r update (operand of the next stencil launch)
   void* cz2;                   // asym only: weight of the -z tap (the density operator, DensityCGSolver3D.py:184)
   int asym;                    // 1: set up by mfs_pcg3d_setup_density
   void* d2;                    // ping-pong partner of the bound d (fused direction update)
@@ -356,7 +433,7 @@ extern "C" {
 size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   const int64_t n = gres[0] * gres[1] * gres[2];
-  return core_ws_bytes() + 6 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096) +
+  return core_ws_bytes() + 7 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096) +
          align_up((size_t)kMaxPartials * 8, 4096) + res_ws_bytes(n, dtype_size(dt));
 }
 
@@ -381,8 +458,9 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->d2 = p + 4 * cs;
   h->cz2 = p + 5 * cs;
   h->asym = 0;
-  h->cls = (unsigned char*)(p + 6 * cs);
-  h->part_rz = (double*)(p + 6 * cs + align_up((size_t)h->n, 4096));
+  h->zb = p + 6 * cs;
+  h->cls = (unsigned char*)(p + 7 * cs);
+  h->part_rz = (double*)(p + 7 * cs + align_up((size_t)h->n, 4096));
   h->resident = env_int("MFS_RESIDENT", -1);
   h->res_w = std::max(1, std::min(kResMaxW, env_int("MFS_RES_W", 64)));
   h->res = ResPlan{};
@@ -664,6 +742,9 @@ extern "C" {
 int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   if (h && h->jacobi) {
     MFS_REQUIRE(h->c.x && h->is_setup, "engine not bound / set up");
+    h->x_owed = false;
+    h->book_pending = false;
+    h->slab_loop = false;
     return jac_begin(h, tol, (hipStream_t)stream);
   }
   if (int e = mfs_pcg3d_begin_local(h, tol, stream)) return e;
@@ -671,20 +752,63 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
 }
 
 static bool native_fuse_ok(const mfs_pcg3d* h);
+static bool jac_fuse_ok(const mfs_pcg3d* h);
 static bool resident_ok(const mfs_pcg3d* h);
 // deferred x update: fused native loop, symmetric operator, prefetch depth 1, x 16-byte aligned
 static bool xdef_ok(const mfs_pcg3d* h) {
   // auto (< 0): on once the CG vectors no longer fit the Infinity Cache (256^3 fp32: 134.7 -> 130.2 us/iteration,
   // fp64: 295 -> 276); below that the extra streams cost the march more than the update kernel saves (128^3: +4 %)
   const bool on = h->defer_x < 0 ? (5.0 * (double)h->n * h->c.elt > 200e6) : (h->defer_x != 0);
-  return on && native_fuse_ok(h) && !h->asym && h->pd < 2 && ((uintptr_t)h->c.x % 16 == 0);
+  return on && (native_fuse_ok(h) || jac_fuse_ok(h)) && !h->asym && h->pd < 2 && ((uintptr_t)h->c.x % 16 == 0);
 }
 
-static bool native_fuse_ok(const mfs_pcg3d* h) {
+// the fused stencil launch can serve the engine as bound (LDS march, whole 16-byte vectors, aligned CG vectors)
+static bool fuse_shape_ok(const mfs_pcg3d* h) {
   const bool vec_in = h->vec_ok && ((uintptr_t)h->c.d % 16 == 0) && ((uintptr_t)h->c.q % 16 == 0) &&
                       ((uintptr_t)h->c.r % 16 == 0);
-  return h->fuse != 0 && !h->jacobi && h->variant == 2 && vec_in && h->Ny >= 3 && h->Nz >= 3 && h->Nx >= 3;
+  return h->fuse != 0 && h->variant == 2 && vec_in && h->Ny >= 3 && h->Nz >= 3 && h->Nx >= 3;
 }
+static bool native_fuse_ok(const mfs_pcg3d* h) { return fuse_shape_ok(h) && !h->jacobi; }
+// ... and the opt-in Jacobi loop in its fused form (same kernel, operand z = r / diag)
+static bool jac_fuse_ok(const mfs_pcg3d* h) { return fuse_shape_ok(h) && h->jacobi && h->pd < 2; }
+
+// one iteration of the fused Jacobi loop: stencil launch (iteration 0: on d_0 = z_0 as begin left it; afterwards forming
+// d_j = z_j + beta d_{j-1} into the other buffer of {bound d, d2}, the deferred x update riding along), r / z update with
+// the two dot products' partials, one-block bookkeeping
+extern "C++" {
+template <typename T, int VEC>
+static int jac_iteration_fused(mfs_pcg3d* h, hipStream_t st) {
+  const int64_t j = h->c.iter_enq;
+  void* d_cur = (j & 1) ? h->d2 : h->c.d;
+  void* d_prev = (j & 1) ? h->c.d : h->d2;
+  const bool xdef = xdef_ok(h);
+  int grid = 0, e;
+  if (j == 0) {
+    if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid))) return e;
+  } else {
+    FuseArgs fz{h->zb, d_prev, d_cur};
+    if (xdef) fz.xdef = h->c.x;
+    if ((e = apply_dispatch(h, d_cur, h->c.q, 1, h->Nx - 1, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e;
+  }
+  h->c.n_part_dq = grid;
+  const int g = core_vec_grid(h->c, true);
+  const int par = (int)(j & 1);
+  if (xdef)
+    hipLaunchKernelGGL((k_jac_update_rz<T, VEC, false>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
+                       (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
+                       h->c.part_dq, h->c.n_part_dq);
+  else
+    hipLaunchKernelGGL((k_jac_update_rz<T, VEC, true>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
+                       (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
+                       h->c.part_dq, h->c.n_part_dq);
+  hipLaunchKernelGGL(k_jac_book, dim3(1), dim3(kBlock), 0, st, h->c.scal, h->c.hist, kHistCap, par, h->c.part_rr, h->part_rz, g);
+  MFS_LAUNCH_CHECK();
+  h->c.n_part_rr = g;
+  if (xdef) h->x_owed = true;
+  ++h->c.iter_enq;
+  return MFS_OK;
+}
+}  // extern "C++"
 
 // the tail-less form of the fused loop (see BookArgs)
 static bool lean_ok(const mfs_pcg3d* h) {
@@ -835,6 +959,14 @@ int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
     if (int e = pcg_close_pending(h, (hipStream_t)stream)) return e;
   if (!h->jacobi && resident_ok(h)) return pcg_iterate_resident(h, n, (hipStream_t)stream);
   if (!h->jacobi && lean_ok(h)) return pcg_iterate_lean(h, n, (hipStream_t)stream);
+  if (h->jacobi && jac_fuse_ok(h) && core_vec_ok(h->c)) {
+    for (int64_t i = 0; i < n; ++i) {
+      const int e = h->dt == MFS_F32 ? jac_iteration_fused<float, 4>(h, (hipStream_t)stream)
+                                     : jac_iteration_fused<double, 2>(h, (hipStream_t)stream);
+      if (e) return e;
+    }
+    return MFS_OK;
+  }
   if (h->jacobi) {
     const bool vec = core_vec_ok(h->c) && ((uintptr_t)h->diag % 16 == 0);
     for (int64_t i = 0; i < n; ++i) {
@@ -856,8 +988,10 @@ int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
 // after a fused native loop the reference's `d` (d of the last completed iteration) may sit in the
 // engine's partner buffer: bring it home to the bound array (iteration count known from a poll)
 static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t st) {
-  if (!native_fuse_ok(h) || iters < 1 || !h->c.d) return MFS_OK;
+  const bool jac = jac_fuse_ok(h) && core_vec_ok(h->c);
+  if (!(native_fuse_ok(h) || jac) || iters < 1 || !h->c.d) return MFS_OK;
   void* cur = ((iters - 1) & 1) ? h->d2 : h->c.d;             // holds d_{iters-1}
+  const void* rsrc = jac ? h->zb : h->c.r;                    // fused Jacobi loop: d = z + beta d
   if (h->x_owed) {                                            // owed: x += alpha_{iters-1} d_{iters-1}
     h->x_owed = false;
     const int grid = core_vec_grid(h->c, true);
@@ -868,14 +1002,14 @@ static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t s
     MFS_LAUNCH_CHECK();
   }
   if (!converged) {                                           // owed: d_iters = r + beta d_{iters-1}
-    const bool vec = ((uintptr_t)cur % 16 == 0) && ((uintptr_t)h->c.r % 16 == 0);
+    const bool vec = ((uintptr_t)cur % 16 == 0) && ((uintptr_t)rsrc % 16 == 0);
     const int grid = core_vec_grid(h->c, vec);
     if (h->dt == MFS_F32) {
-      if (vec) hipLaunchKernelGGL((k_d_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)h->c.r, h->n, h->c.scal);
-      else hipLaunchKernelGGL((k_d_axpy<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)h->c.r, h->n, h->c.scal);
+      if (vec) hipLaunchKernelGGL((k_d_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)rsrc, h->n, h->c.scal);
+      else hipLaunchKernelGGL((k_d_axpy<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)rsrc, h->n, h->c.scal);
     } else {
-      if (vec) hipLaunchKernelGGL((k_d_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)h->c.r, h->n, h->c.scal);
-      else hipLaunchKernelGGL((k_d_axpy<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)h->c.r, h->n, h->c.scal);
+      if (vec) hipLaunchKernelGGL((k_d_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)rsrc, h->n, h->c.scal);
+      else hipLaunchKernelGGL((k_d_axpy<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)rsrc, h->n, h->c.scal);
     }
     MFS_LAUNCH_CHECK();
   }
@@ -908,7 +1042,8 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
 int mfs_pcg3d_loop_info(mfs_pcg3d* h) {
   if (!h || !h->c.x) return 0;
   const bool res = !h->jacobi && resident_ok(h);
-  return (native_fuse_ok(h) ? 1 : 0) | (!res && xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0) | (res ? 8 : 0);
+  const bool jf = jac_fuse_ok(h) && core_vec_ok(h->c);
+  return ((native_fuse_ok(h) || jf) ? 1 : 0) | (!res && xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0) | (res ? 8 : 0);
 }
 
 // for callers that drive begin / iterate themselves: settles what the loop forms owe (the deferred x update, the
