@@ -170,6 +170,51 @@ __device__ __forceinline__ bool last_block_total(double* __restrict__ partial, i
   return true;
 }
 
+// the same tail for TWO partial-sum arrays filled by one kernel (the fused Jacobi loop's r.r and r.z): one ticket round,
+// both totals in block_total_of's order
+__device__ __forceinline__ bool last_block_total2(double* __restrict__ pa, double* __restrict__ pb, int my_slot, double va,
+                                                  double vb, int count, unsigned* ticket, unsigned nblocks, double* ta,
+                                                  double* tb) {
+  __shared__ int s_last2;
+  __shared__ double s_ta, s_tb;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(pa + my_slot, va, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pb + my_slot, vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned nsh = nblocks < 8u ? nblocks : 8u;
+    const unsigned shard = blockIdx.x % nsh;
+    const unsigned in_shard = (nblocks - shard + nsh - 1) / nsh;
+    unsigned* sc = ticket + shard * kTicketStride;
+    bool last = false;
+    if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+      __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned* top = ticket + 8 * kTicketStride;
+      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1) {
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = true;
+      }
+    }
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last2 = last;
+  }
+  __syncthreads();
+  if (!s_last2) return false;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < count; i += kBlock) {
+    a += __hip_atomic_load(pa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b += __hip_atomic_load(pb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const double t1 = block_sum<kBlock>(a);
+  const double t2 = block_sum<kBlock>(b);
+  if (threadIdx.x == 0) { s_ta = t1; s_tb = t2; }
+  __syncthreads();
+  *ta = s_ta; *tb = s_tb;
+  return true;
+}
+
 // the bookkeeping that closes an iteration (ONE thread): convergence test (:218), history, iteration
 // count, delta ring, beta (:220)
 __device__ __forceinline__ void cg_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,

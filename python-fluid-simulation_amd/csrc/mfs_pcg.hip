@@ -184,12 +184,32 @@ k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__
 // d = z + beta d_old on the fly with the plain loop's fused kernel (k_pcg_apply_march FUSE, operand `r` := z), the
 // deferred x update riding along as there.  12 + 2 scalars per cell and iteration instead of 6 + 8 + 5 in three full passes.
 // XUPD: x += alpha d here (cache-resident sizes); otherwise the next stencil launch does it (XDEF).
+// cls (compressed coefficient access on): the class byte of a z-vector stands for its diagonal unless the vector is MIXED
+// (ZERO: 0 -> z = 0; REGULAR: 6; a class leaves the never-computed boundary cells of a vector open, where r is exactly 0 and
+// z therefore 0 either way).  The LAST block to finish closes the iteration (last_block_total2 + jac_book): no third launch.
+__device__ __forceinline__ void jac_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
+                                         double rr, double rz) {
+  const double delta = scal[S_RING + par], dq = scal[S_DQ];
+  const int64_t it = (int64_t)scal[S_ITERS];
+  if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+  scal[S_ITERS] = (double)(it + 1);
+  scal[S_RING + (par ^ 1)] = rz;
+  scal[S_RR] = rr;
+  scal[S_RZ] = rz;
+  scal[S_DELTA] = delta;
+  scal[S_LASTRR] = rr;
+  scal[S_ALPHA] = delta / dq;
+  if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
+  else if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rz / delta;
+}
+
 template <typename T, int VEC, bool XUPD>
 __global__ void __launch_bounds__(kBlock)
 k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q,
                 const T* __restrict__ diag, T* __restrict__ z, int64_t n, double* __restrict__ scal,
                 double* __restrict__ part_rr, double* __restrict__ part_rz, int par, const double* __restrict__ part_dq,
-                int npart) {
+                int npart, const unsigned char* __restrict__ cls, double* __restrict__ hist, int64_t hist_cap,
+                unsigned* __restrict__ ticket) {
   const double dn = scal[S_DONE];
   const double delta = scal[S_RING + par];
   const double dq = block_total_of(part_dq, npart);
@@ -200,7 +220,17 @@ k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
     if (vec) {
       vec_t<T, VEC> rv = vload<T, VEC>(r + i), zv;
-      const vec_t<T, VEC> qv = vload<T, VEC>(q + i), gv = vload<T, VEC>(diag + i);
+      const vec_t<T, VEC> qv = vload<T, VEC>(q + i);
+      vec_t<T, VEC> gv;
+      if (cls) {
+        const unsigned char c = cls[i / VEC];
+        const T g0 = c == kClsRegular ? (T)6 : (T)0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) gv[j] = g0;
+        if (c == kClsMixed) gv = vload<T, VEC>(diag + i);
+      } else {
+        gv = vload<T, VEC>(diag + i);
+      }
       if (XUPD) {
         vec_t<T, VEC> xv = vload<T, VEC>(x + i);
         const vec_t<T, VEC> dv = vload<T, VEC>(d + i);
@@ -230,29 +260,9 @@ k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
   });
   const double t1 = block_sum<kBlock>(arr);
   const double t2 = block_sum<kBlock>(arz);
-  if (threadIdx.x == 0) { part_rr[blockIdx.x] = t1; part_rz[blockIdx.x] = t2; }
-}
-
-// one block: closes a fused Jacobi iteration (k_jac_update_d's bookkeeping: test r.r < tol^2, history, delta <- r.z, alpha, beta)
-static __global__ void __launch_bounds__(kBlock)
-k_jac_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
-           const double* __restrict__ part_rr, const double* __restrict__ part_rz, int npart) {
-  if (scal[S_DONE] != 0.0) return;
-  const double rr = block_total_of(part_rr, npart);
-  const double rz = block_total_of(part_rz, npart);
-  if (threadIdx.x != 0) return;
-  const double delta = scal[S_RING + par], dq = scal[S_DQ];
-  const int64_t it = (int64_t)scal[S_ITERS];
-  if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
-  scal[S_ITERS] = (double)(it + 1);
-  scal[S_RING + (par ^ 1)] = rz;
-  scal[S_RR] = rr;
-  scal[S_RZ] = rz;
-  scal[S_DELTA] = delta;
-  scal[S_LASTRR] = rr;
-  scal[S_ALPHA] = delta / dq;
-  if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
-  else if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rz / delta;
+  double rr, rz;
+  if (!last_block_total2(part_rr, part_rz, blockIdx.x, t1, t2, gridDim.x, ticket, gridDim.x, &rr, &rz)) return;
+  if (threadIdx.x == 0) jac_book(scal, hist, hist_cap, par, rr, rz);
 }
 
 }  // namespace mfs
@@ -793,15 +803,15 @@ static int jac_iteration_fused(mfs_pcg3d* h, hipStream_t st) {
   h->c.n_part_dq = grid;
   const int g = core_vec_grid(h->c, true);
   const int par = (int)(j & 1);
+  const unsigned char* cls = h->compress != 0 ? h->cls : nullptr;      // class bytes are valid whenever the march uses them
   if (xdef)
     hipLaunchKernelGGL((k_jac_update_rz<T, VEC, false>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
                        (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
-                       h->c.part_dq, h->c.n_part_dq);
+                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets);
   else
     hipLaunchKernelGGL((k_jac_update_rz<T, VEC, true>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
                        (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
-                       h->c.part_dq, h->c.n_part_dq);
-  hipLaunchKernelGGL(k_jac_book, dim3(1), dim3(kBlock), 0, st, h->c.scal, h->c.hist, kHistCap, par, h->c.part_rr, h->part_rz, g);
+                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets);
   MFS_LAUNCH_CHECK();
   h->c.n_part_rr = g;
   if (xdef) h->x_owed = true;
