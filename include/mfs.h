@@ -199,9 +199,11 @@ int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
 /* form of the native loop for the engine as bound: bit 0 = direction update fused into the stencil launch,
  * bit 1 = x update deferred into it too, bit 2 = Jacobi loop, bit 3 = resident small-grid loop (mfs_pcg3d_set_resident) */
 int mfs_pcg3d_loop_info(mfs_pcg3d* h);
-/* OPT-IN Jacobi preconditioning of the native loop (default off; env MFS_JACOBI=1): z = r / diag fused into the
- * two vector phases, delta = r.z, convergence test unchanged (r.r < tol^2).  NOT the reference's algorithm -- the
- * reference's CG is unpreconditioned and its residual history cannot be matched with this on.  One GPU only.  */
+/* OPT-IN Jacobi preconditioning of the native loop (default off; env MFS_JACOBI=1): delta = r.z with z = r / diag,
+ * convergence test unchanged (r.r < tol^2).  Fused form (default where the fused direction update is available): the r
+ * update stores z and closes the iteration, the next stencil launch forms d = z + beta d (2 launches per iteration);
+ * otherwise z is formed inside the two vector phases (3 launches).  NOT the reference's algorithm -- the reference's CG
+ * is unpreconditioned and its residual history cannot be matched with this on.  One GPU only (the slab loops ignore it). */
 int mfs_pcg3d_set_jacobi(mfs_pcg3d* h, int on);
 /* fused direction update (default on, native loop only): `d = r + beta d` is formed inside the next
  * stencil launch instead of in a pass of its own; bit-identical; d ping-pongs with an engine buffer */

@@ -1050,7 +1050,8 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
 // what the native loop will do for the engine as bound: bit 0 fused direction update, bit 1 deferred x update, bit 2 Jacobi,
 // bit 3 resident small-grid loop
 int mfs_pcg3d_loop_info(mfs_pcg3d* h) {
-  if (!h || !h->c.x) return 0;
+  if (!h) return 0;
+  if (!h->c.x) return h->jacobi ? 4 : 0;          // not bound yet: only the mode is known
   const bool res = !h->jacobi && resident_ok(h);
   const bool jf = jac_fuse_ok(h) && core_vec_ok(h->c);
   return ((native_fuse_ok(h) || jf) ? 1 : 0) | (!res && xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0) | (res ? 8 : 0);

@@ -146,6 +146,14 @@ class SlabCG(_BoundedCollectives):
         if self.window is not None:
             ops.attach_p2p(self.window)
         self._bc_init()
+        # The opt-in Jacobi preconditioner is an extra of the single-GPU loop: the slab loops run the reference's
+        # unpreconditioned CG (same solution, the reference's iteration count).  Say so once instead of silently dropping
+        # to the collective loop with the flag ignored.
+        info = ops.loop_info() if hasattr(ops, "loop_info") else {}
+        if info.get("jacobi"):
+            warnings.warn("SlabCG: Jacobi preconditioning is a single-GPU extra -- the slab loop runs the reference's "
+                          "unpreconditioned CG (mfs_pcg3d_set_jacobi switched off on this engine)", RuntimeWarning, stacklevel=2)
+            ops.set_jacobi(False)
         self._p2p_active = None          # which loop the last begin() / solve() took (None: none yet)
         self.downgraded = ""             # why a given window is NOT being used (empty: it is, or none was given)
 
