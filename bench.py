@@ -221,6 +221,119 @@ def notebook_grid_leg(torch, dev):
             "us_per_iteration": round(dt / n * 1e6, 2), "iters_per_s": round(n / dt, 1), "parity_check": pc}
 
 
+def viscosity_leg(torch, dev, n, steps, with_parity):
+    """BASELINE config 3 (`ViscosityCGSolver3D`, buckling-like scene, fp32 state) at n^3: time per CG iteration of the native
+    loop, the operator apply (k_vcg_apply_march, csrc/mfs_vcg_march.h) bracketed by HIP events inside real iterations against
+    its algorithmic bytes (13 scalars + 1 packed mask byte per cell), and -- config 3's own size -- the
+    first 10 iterations against the oracle's C restatement of the viscosity CG."""
+    import numpy as np
+    from mfs import scenes
+    import solver.ViscosityCGSolver3D as V
+    gres = (n, n, n)
+    sc = scenes.viscosity_scene_3d(gres, seed=3, device=dev)
+    s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision="fp32", device=dev)
+    scale, mu = sc["dt"] / s.cell_vol / sc["rho"], sc["mu"]
+    torch.div(sc["lvol"], s.cell_vol * 0.125, out=s.vol)
+    s.x_x.copy_(sc["vx"]); s.x_y.copy_(sc["vy"]); s.x_z.copy_(sc["vz"])
+    V.extrapolate(gres, 3, s.x_x, s.x_y, s.x_z, sc["sphi"])
+    V.initialize_solver(gres, scale, mu, s.x_x, s.x_y, s.x_z, sc["sphi"], sc["sv"], s.vol, s.b_x, s.b_y, s.b_z)
+    e, f = s._engine, s._flat
+    e.setup(scale, mu, sc["sphi"], s.vol)
+    e.bind(f["b"], f["x"], f["d"], f["r"], f["q"])
+    host = lambda t: t.double().cpu().numpy()  # noqa: E731
+    out = {"workload": f"ViscosityCGSolver3D {n}^3 buckling-like scene, fp32 state", "apply_kernel": e.apply_kernel(),
+           "loop": "fused" if e.loop_info()["fused"] else "three launches (march | r update | direction + x update)"}
+    if with_parity:
+        from oracle import cbaseline
+        iters, tol = 10, 1e-5
+        x0, b = host(f["x"]), host(f["b"])
+        vol = s.vol.float().double().cpu().numpy()          # fp32 state stores the class samples in fp32: same values
+        e.begin(0.0)
+        e.iterate(iters)
+        e.finish()
+        torch.cuda.synchronize()
+        h = e.history()[: 2 * iters + 1]
+        ref = cbaseline.visc_cg(gres, scale, mu, b, x0, host(sc["sphi"]), vol, 0.0, iters, 2 * iters + 1)
+        dev_h = float(np.max(np.abs(h - ref["history"]) / np.abs(ref["history"])))
+        dev_x = float(np.max(np.abs(host(f["x"]) - ref["x"])) / np.max(np.abs(ref["x"])))
+        ok = bool(len(h) == len(ref["history"]) == 2 * iters + 1 and dev_h < tol and dev_x < tol)
+        out["parity_check"] = {"iterations": iters, "history_max_rel_dev": dev_h, "x_max_dev_rel_to_max": dev_x,
+                               "tolerance": tol, "ok": ok, "oracle": "oracle/mfs_oracle_c.c (viscosity operator + CG loop, fp64)"}
+        if not ok:
+            raise AssertionError(f"bench viscosity parity self-check failed: {out}")
+        s.x_x.copy_(sc["vx"]); s.x_y.copy_(sc["vy"]); s.x_z.copy_(sc["vz"])
+        V.extrapolate(gres, 3, s.x_x, s.x_y, s.x_z, sc["sphi"])
+    e.begin(0.0)
+    e.iterate(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e.iterate(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = e.poll()
+    assert st["iterations"] == 10 + steps and st["delta"] == st["delta"], st
+    # the apply launch inside real iterations (phase form of the same kernels: the events bracket one launch each)
+    reps = 24
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b_ in ev:
+        a.record()
+        e.phase_apply()
+        b_.record()
+        e.phase_reduce(0)
+        e.phase_update_xr()
+        e.phase_reduce(1)
+        e.phase_update_d()
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b_) for a, b_ in ev) / reps
+    cells = n ** 3
+    ab = cells * (13 * 4 + 1)
+    out.update({"us_per_iteration": round(dt / steps * 1e6, 2), "Mcells_per_s": round(cells * steps / dt / 1e6, 1),
+                "apply": {"kernel": "k_vcg_apply_march<float, 4> (q = A d, three coupled components, d.q partials)",
+                          "algorithmic_bytes": ab, "kernel_ms": round(ms, 5), "achieved": round(ab / (ms * 1e-3) / 1e9, 1),
+                          "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s"}})
+    del s, e, f, sc
+    torch.cuda.empty_cache()
+    return out
+
+
+def jacobi_leg(args, torch, dev, tdt, lgres, seed):
+    """the OPT-IN Jacobi-preconditioned loop (north_star: "Jacobi-precondition fused"; NOT the reference's iteration) on the
+    bench workload: time per iteration of the fused two-launch form, and what it buys -- iterations and time of a whole
+    solve at the reference's default tol = 1e-3 against the reference's CG on the same engine."""
+    from mfs.pcg import PcgEngine
+    wx, wy, wz, lphi, (b, x, d, r, q) = build_problem(torch, dev, tdt, lgres, lgres, seed, None)
+    eng = PcgEngine(lgres, tdt, dev)
+    eng.setup(lphi, wx, wy, wz)
+    eng.bind(b, x, d, r, q)
+    out = {}
+    cap = lgres[0] * lgres[1] * lgres[2]
+    for jac in (False, True):
+        eng.set_jacobi(jac)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok, it = eng.solve(1e-3, cap, 32)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        assert ok, "the bench problem did not converge at tol 1e-3"
+        out["jacobi" if jac else "reference_cg"] = {"iterations": int(it), "solve_ms": round(ms, 2)}
+    steps = max(50, min(args.steps, 200))
+    eng.begin(0.0)
+    eng.iterate(20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.iterate(steps)
+    eng.finish()
+    torch.cuda.synchronize()
+    info = eng.loop_info()
+    out["jacobi"].update({"us_per_iteration": round((time.perf_counter() - t0) / steps * 1e6, 2),
+                          "loop": "fused: stencil launch forms d = z + beta d (z = r / diag stored by the r update), 2 launches"
+                                  if info["fused_direction_update"] else "three launches"})
+    out["note"] = "opt-in (jacobi=True / MFS_JACOBI=1), off by default: not the reference's residual history, same solution to tol"
+    del eng, wx, wy, wz, lphi, b, x, d, r, q
+    torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks as child processes
     (one per GPU, `python -m torch.distributed.run`), relay their output -- rank 0 prints the JSON line -- and return
@@ -431,6 +544,8 @@ def main():
     parity = None
     f64_line = None
     nb_line = None
+    visc_line = None
+    jac_line = None
     if rank == 0 and not args.timed_loop_only:
         Nx, Ny, Nz = lgres
         cells_l = Nx * Ny * Nz
@@ -568,6 +683,12 @@ def main():
         # ---- the reference's own grid (launch-bound size): resident loop
         if world == 1 and transport == "single" and not args.no_f64_line:
             nb_line = notebook_grid_leg(torch, dev)
+        # ---- BASELINE config 3 (viscosity CG 128^3, with its own oracle check) and the same solver beyond the Infinity
+        # Cache; the opt-in Jacobi loop on the bench workload
+        if world == 1 and transport == "single" and args.dtype == "f32" and not args.no_f64_line and not args.local_grid:
+            visc_line = {"config3_128": viscosity_leg(torch, dev, 128, 200, True),
+                         "n256": viscosity_leg(torch, dev, 256, 60, False)}
+            jac_line = jacobi_leg(args, torch, dev, tdt, lgres, seed)
     if world > 1:
         dist.barrier()
 
@@ -605,6 +726,10 @@ def main():
             out["f64_state"] = f64_line
         if nb_line is not None:
             out["notebook_grid"] = nb_line
+        if visc_line is not None:
+            out["viscosity"] = visc_line
+        if jac_line is not None:
+            out["jacobi_preconditioned"] = jac_line
         if shared:
             out["rehearsal"] = "all ranks share cuda:0 over gloo (MFS_BENCH_SHARED_GPU=1): code-path check, not a measurement"
         if tinfo:
