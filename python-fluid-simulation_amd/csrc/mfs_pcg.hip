@@ -187,9 +187,10 @@ k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__
 // cls (compressed coefficient access on): the class byte of a z-vector stands for its diagonal unless the vector is MIXED
 // (ZERO: 0 -> z = 0; REGULAR: 6; a class leaves the never-computed boundary cells of a vector open, where r is exactly 0 and
 // z therefore 0 either way).  The LAST block to finish closes the iteration (last_block_total2 + jac_book): no third launch.
+// (dq comes as a VALUE: scal[S_DQ] is a plain store of another workgroup of the same launch, possibly behind another XCD's L2)
 __device__ __forceinline__ void jac_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
-                                         double rr, double rz) {
-  const double delta = scal[S_RING + par], dq = scal[S_DQ];
+                                         double dq, double rr, double rz) {
+  const double delta = scal[S_RING + par];
   const int64_t it = (int64_t)scal[S_ITERS];
   if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
   scal[S_ITERS] = (double)(it + 1);
@@ -262,7 +263,7 @@ k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
   const double t2 = block_sum<kBlock>(arz);
   double rr, rz;
   if (!last_block_total2(part_rr, part_rz, blockIdx.x, t1, t2, gridDim.x, ticket, gridDim.x, &rr, &rz)) return;
-  if (threadIdx.x == 0) jac_book(scal, hist, hist_cap, par, rr, rz);
+  if (threadIdx.x == 0) jac_book(scal, hist, hist_cap, par, dq, rr, rz);
 }
 
 }  // namespace mfs
