@@ -120,7 +120,17 @@ def build_problem(torch, dev, tdt, lgres, ggrid, seed, x_range):
     wy = torch.zeros((lgres[0], lgres[1] + 1, lgres[2]), dtype=tdt, device=dev)
     wz = torch.zeros((lgres[0], lgres[1], lgres[2] + 1), dtype=tdt, device=dev)
     S.compute_solid_frac(lgres, sc["sphi"], wx, wy, wz)
-    b, x, d, r, q = (torch.zeros(lgres, dtype=tdt, device=dev) for _ in range(5))
+    stag = int(os.environ.get("MFS_BENCH_STAGGER", "-1"))
+    if stag >= 0:
+        # A/B knob: the five CG vectors carved out of ONE allocation, vector k starting k * stag bytes past its natural
+        # place (a multiple of 16 bytes) -- does the relative placement of the streams matter?  (profiles/r02_placement_ab.txt)
+        n = lgres[0] * lgres[1] * lgres[2]
+        esz = torch.empty(0, dtype=tdt).element_size()
+        pad = (stag // esz) if stag else 0
+        big = torch.zeros(5 * (n + 4 * pad) + 64, dtype=tdt, device=dev)
+        b, x, d, r, q = (big[k * (n + pad): k * (n + pad) + n].view(lgres) for k in range(5))
+    else:
+        b, x, d, r, q = (torch.zeros(lgres, dtype=tdt, device=dev) for _ in range(5))
     P.initialize_solver(sc["cell_size"], lgres, sc["vx"], sc["vy"], sc["vz"], sc["sphi"], sc["sv"], sc["lphi"],
                         b, wx, wy, wz)
     lphi = sc["lphi"]

@@ -37,6 +37,23 @@
 #define MFS_VMARCH_MIN_WAVES 2     // waves per SIMD the kernel is compiled for (256 VGPRs)
 #endif
 
+// A/B knob (tools/build_variant.sh): wave priority around the fp64 row arithmetic.  1: rows run at raised priority (the
+// other wave of the SIMD gets the issue slots the rows leave: its LDS / vector-memory phases); 2: the reverse (memory
+// phases first).  0 (default): none.
+#ifndef MFS_VM_PRIO
+#define MFS_VM_PRIO 0
+#endif
+#if MFS_VM_PRIO == 1
+#define MFS_VM_ROWS_BEGIN() __builtin_amdgcn_s_setprio(2)
+#define MFS_VM_ROWS_END() __builtin_amdgcn_s_setprio(0)
+#elif MFS_VM_PRIO == 2
+#define MFS_VM_ROWS_BEGIN() __builtin_amdgcn_s_setprio(0)
+#define MFS_VM_ROWS_END() __builtin_amdgcn_s_setprio(2)
+#else
+#define MFS_VM_ROWS_BEGIN() do {} while (0)
+#define MFS_VM_ROWS_END() do {} while (0)
+#endif
+
 #ifndef MFS_VM_FUSE_TOP
 #define MFS_VM_FUSE_TOP 0       // FUSE: 1 = all three components of plane x+2 requested at the top of the step, 0 = one per phase
 #endif
@@ -556,7 +573,9 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       { const T t = vm_from_right<T>(rg.exzc[0]); rg.exzzr = fixr ? rg.exzzr : t; }      // EXZ[x, y, z0+VEC]
       MFS_VM_STAMP(3);                                           // u: image reads (issued and landed)
       V qu;
+      MFS_VM_ROWS_BEGIN();
       vm_row<T, VEC, 0>(rg, k1, k2, msk, qu, first, last, active, acc);
+      MFS_VM_ROWS_END();
       MFS_VM_STAMP(4);                                           // u: rows (includes the wait for this step's class samples)
       if (active) vm_store<T, VEC, true, NT>(ox + (int64_t)x * su + o_uv, qu, first, last);
       MFS_VM_PIN();
@@ -585,7 +604,9 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       { const T t = vm_from_right<T>(rg.eyzc[0]); rg.eyzzr = fixr ? rg.eyzzr : t; }      // EYZ[x, y, z0+VEC]
       MFS_VM_STAMP(6);                                           // v: image reads
       V qv;
+      MFS_VM_ROWS_BEGIN();
       vm_row<T, VEC, 1>(rg, k1, k2, msk, qv, first, last, active, acc);
+      MFS_VM_ROWS_END();
       MFS_VM_STAMP(7);                                           // v: rows
       if (active) vm_store<T, VEC, true, NT>(oy + (int64_t)x * sv + o_uv, qv, first, last);
       MFS_VM_PIN();
@@ -616,7 +637,9 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       { const T t = vm_from_left<T>(rg.cc[VEC - 1]); rg.czl = fixl ? rg.czl : t; }        // C[x, y, z0-1]
       MFS_VM_STAMP(9);                                           // w: image reads
       V qw;
+      MFS_VM_ROWS_BEGIN();
       vm_row<T, VEC, 2>(rg, k1, k2, msk, qw, first, last, active, acc);
+      MFS_VM_ROWS_END();
       MFS_VM_STAMP(10);                                          // w: rows
       if (active) vm_store<T, VEC, false, NT>(oz + (int64_t)x * sw + o_w, qw, first, last);
       MFS_VM_PIN();
