@@ -203,7 +203,9 @@ int mfs_pcg3d_loop_info(mfs_pcg3d* h);
  * convergence test unchanged (r.r < tol^2).  Fused form (default where the fused direction update is available): the r
  * update stores z and closes the iteration, the next stencil launch forms d = z + beta d (2 launches per iteration);
  * otherwise z is formed inside the two vector phases (3 launches).  NOT the reference's algorithm -- the reference's CG
- * is unpreconditioned and its residual history cannot be matched with this on.  One GPU only (the slab loops ignore it). */
+ * is unpreconditioned and its residual history cannot be matched with this on.  Runs in the single-GPU loop and in the
+ * WINDOW slab loop (mfs_pcg3d_slab_*: z as the operand of the edge / interior direction updates, r.r and r.z all-reduced
+ * in the tail of the r / z update); the phase API of the collective loop has no Jacobi form. */
 int mfs_pcg3d_set_jacobi(mfs_pcg3d* h, int on);
 /* fused direction update (default on, native loop only): `d = r + beta d` is formed inside the next
  * stencil launch instead of in a pass of its own; bit-identical; d ping-pongs with an engine buffer */

@@ -204,18 +204,21 @@ __device__ __forceinline__ void jac_book(double* __restrict__ scal, double* __re
   else if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rz / delta;
 }
 
+struct JacSlab { int on; P2pDev pd; int ring[2]; unsigned tag[2]; };
+
 template <typename T, int VEC, bool XUPD>
 __global__ void __launch_bounds__(kBlock)
 k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q,
                 const T* __restrict__ diag, T* __restrict__ z, int64_t n, double* __restrict__ scal,
                 double* __restrict__ part_rr, double* __restrict__ part_rz, int par, const double* __restrict__ part_dq,
                 int npart, const unsigned char* __restrict__ cls, double* __restrict__ hist, int64_t hist_cap,
-                unsigned* __restrict__ ticket) {
+                unsigned* __restrict__ ticket, JacSlab sl) {
   const double dn = scal[S_DONE];
   const double delta = scal[S_RING + par];
-  const double dq = block_total_of(part_dq, npart);
+  // d.q: folded from the stencil launch's partials (one GPU) or the all-reduced scalar (slab loop: npart == 0)
+  const double dq = npart > 0 ? block_total_of(part_dq, npart) : scal[S_DQ];
   if (dn != 0.0) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
+  if (npart > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
   const double alpha = delta / dq;
   double arr = 0.0, arz = 0.0;
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
@@ -263,6 +266,15 @@ k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
   const double t2 = block_sum<kBlock>(arz);
   double rr, rz;
   if (!last_block_total2(part_rr, part_rz, blockIdx.x, t1, t2, gridDim.x, ticket, gridDim.x, &rr, &rz)) return;
+  if (sl.on) {      // slab loop: both dot products over all ranks (two episodes of the window all-reduce), then the bookkeeping
+    if (threadIdx.x >= kWave) return;
+    bool ok;
+    rr = slab_allreduce_wave(sl.pd, sl.ring[0], sl.tag[0], rr, &ok);
+    if (!ok) { if (threadIdx.x == 0) slab_fail(scal, 1); return; }
+    rr = __shfl(rr, 0, kWave);
+    rz = slab_allreduce_wave(sl.pd, sl.ring[1], sl.tag[1], rz, &ok);
+    if (!ok) { if (threadIdx.x == 0) slab_fail(scal, 1); return; }
+  }
   if (threadIdx.x == 0) jac_book(scal, hist, hist_cap, par, dq, rr, rz);
 }
 
@@ -808,11 +820,11 @@ static int jac_iteration_fused(mfs_pcg3d* h, hipStream_t st) {
   if (xdef)
     hipLaunchKernelGGL((k_jac_update_rz<T, VEC, false>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
                        (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
-                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets);
+                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets, JacSlab{});
   else
     hipLaunchKernelGGL((k_jac_update_rz<T, VEC, true>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
                        (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
-                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets);
+                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets, JacSlab{});
   MFS_LAUNCH_CHECK();
   h->c.n_part_rr = g;
   if (xdef) h->x_owed = true;
@@ -1102,7 +1114,8 @@ int64_t mfs_pcg3d_history(mfs_pcg3d* h, double* out_host, int64_t cap, mfs_strea
 // Slab loop over peer-to-peer windows (mfs_pcg_slab.h): one rank of a grid cut into x-slabs.
 // ----------------------------------------------------------------------------------------------
 static bool slab_ok(const mfs_pcg3d* h) {
-  return h->p2p && h->p2p->connected && native_fuse_ok(h) && !h->jacobi &&
+  // (the opt-in Jacobi loop too, in its fused form: the same kernels with z = r / diag as the operand of the direction update)
+  return h->p2p && h->p2p->connected && (native_fuse_ok(h) || (jac_fuse_ok(h) && core_vec_ok(h->c))) &&
          (size_t)h->Ny * h->Nz * h->c.elt == h->p2p->plane_bytes;
 }
 
@@ -1122,6 +1135,11 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
   const int64_t plane_elems = (int64_t)h->Ny * h->Nz;
   const unsigned halo_tag = 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)((j + 1) & 0xfffff);
   int e_;
+  // Jacobi (opt-in): the operand of the direction update is z = r / diag as stored by the previous r / z update, and an
+  // iteration has three all-reduce episodes (d.q, r.r, r.z) instead of two; begin used episodes 0 and 1
+  const bool jac = h->jacobi != 0;
+  const T* rsrc = (const T*)(jac ? h->zb : h->c.r);
+  const int64_t ep_dq = jac ? 3 * j + 2 : 2 * j + 1, ep_rr = jac ? 3 * j + 3 : 2 * j + 2, ep_rz = 3 * j + 4;
   // deferred x update (as in the native loop): x += alpha_{j-1} d_{j-1} rides in this iteration's edge / interior launches
   const bool xdef = xdef_ok(h) && L - 2 > 2;
   // 1. edge planes of d_j: local + into the neighbours' windows -- on the second stream, behind everything
@@ -1138,7 +1156,7 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
       hipLaunchKernelGGL((k_slab_edge_d<T, VEC, true>), dim3(grid), dim3(kBlock), 0, se, (const T*)nullptr, (const T*)d_cur,
                          (T*)nullptr, plane_elems, e, h->c.scal, p->dev, par, halo_tag, (T*)nullptr);
     else
-      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, false>), dim3(grid), dim3(kBlock), 0, se, (const T*)h->c.r, (const T*)d_prev,
+      hipLaunchKernelGGL((k_slab_edge_d<T, VEC, false>), dim3(grid), dim3(kBlock), 0, se, rsrc, (const T*)d_prev,
                          d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag, xdef ? (T*)h->c.x : (T*)nullptr);
     MFS_LAUNCH_CHECK();
   }
@@ -1150,7 +1168,7 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     if (j == 0) {
       if ((e_ = apply_dispatch(h, d_cur, h->c.q, 2, L - 2, h->c.part_dq, 1, st, &grid))) return e_;
     } else {
-      FuseArgs fz{h->c.r, d_prev, d_cur};
+      FuseArgs fz{rsrc, d_prev, d_cur};
       if (xdef) fz.xdef = h->c.x;
       if ((e_ = apply_dispatch(h, d_cur, h->c.q, 2, L - 2, h->c.part_dq, 1, st, &grid, 0, 0, &fz))) return e_;
     }
@@ -1165,11 +1183,32 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
                        (const T*)h->diag, (const T*)h->cx, (const T*)h->cy, (const T*)h->cz,
                        (const T*)(h->asym ? h->cz2 : h->cz), L, h->Ny, h->Nz, e,
                        h->c.part_dq, n_part, h->c.scal, p->dev, par, halo_tag, h->c.tickets + kTicketWords,
-                       (int)((2 * j + 1) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 1));
+                       (int)(ep_dq & (kArRing - 1)), slab_ar_tag(p, ep_dq));
     MFS_LAUNCH_CHECK();
     n_part += grid;
   }
   h->c.n_part_dq = n_part;
+  if (jac) {
+    // 4'. r / z update over the owned planes; its last block: r.r and r.z over all ranks + bookkeeping
+    const int64_t off = plane_elems, cnt = plane_elems * (L - 2);
+    const int g = std::max(1, (int)std::min<int64_t>(core_vec_grid(h->c, true), (cnt / VEC + kBlock - 1) / kBlock));
+    const unsigned char* cls = h->compress != 0 ? h->cls + off / VEC : nullptr;
+    JacSlab sl{1, p->dev, {(int)(ep_rr & (kArRing - 1)), (int)(ep_rz & (kArRing - 1))}, {slab_ar_tag(p, ep_rr), slab_ar_tag(p, ep_rz)}};
+    if (xdef) {
+      h->x_owed = true;
+      hipLaunchKernelGGL((k_jac_update_rz<T, VEC, false>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x + off, (const T*)d_cur + off,
+                         (T*)h->c.r + off, (const T*)h->c.q + off, (const T*)h->diag + off, (T*)h->zb + off, cnt, h->c.scal,
+                         h->c.part_rr, h->part_rz, par, h->c.part_dq, 0, cls, h->c.hist, kHistCap, h->c.tickets, sl);
+    } else {
+      hipLaunchKernelGGL((k_jac_update_rz<T, VEC, true>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x + off, (const T*)d_cur + off,
+                         (T*)h->c.r + off, (const T*)h->c.q + off, (const T*)h->diag + off, (T*)h->zb + off, cnt, h->c.scal,
+                         h->c.part_rr, h->part_rz, par, h->c.part_dq, 0, cls, h->c.hist, kHistCap, h->c.tickets, sl);
+    }
+    MFS_LAUNCH_CHECK();
+    h->c.n_part_rr = g;
+    ++h->c.iter_enq;
+    return MFS_OK;
+  }
   // 4. x, r update (r only when the x update is deferred); its last block: r.r over all ranks + bookkeeping
   if (xdef) {
     h->x_owed = true;
@@ -1229,6 +1268,23 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;
   if (int e = apply_dispatch(h, h->c.x, h->c.q, 1, h->Nx - 1, h->c.part_dq, 0, st, &grid)) return e;  // q = A x (:201)
+  if (h->jacobi) {     // r = b - q, d = z = r / diag, both dot products over all ranks (episodes 0 and 1), delta0 = r.z
+    const int g2 = std::max(1, (int)std::min<int64_t>(h->c.grid_vec, (h->n + kBlock - 1) / kBlock));
+    if (h->dt == MFS_F32)
+      hipLaunchKernelGGL((k_jac_init<float>), dim3(g2), dim3(kBlock), 0, st, (const float*)h->c.b, (const float*)h->c.q,
+                         (const float*)h->diag, (float*)h->c.d, (float*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+    else
+      hipLaunchKernelGGL((k_jac_init<double>), dim3(g2), dim3(kBlock), 0, st, (const double*)h->c.b, (const double*)h->c.q,
+                         (const double*)h->diag, (double*)h->c.d, (double*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+    h->c.n_part_rr = g2;
+    hipLaunchKernelGGL(k_slab_allreduce_rr, dim3(1), dim3(kBlock), 0, st, h->c.part_rr, g2, h->c.scal, h->p2p->dev, 0,
+                       slab_ar_tag(h->p2p, 0), (int)S_RR);
+    hipLaunchKernelGGL(k_slab_allreduce_rr, dim3(1), dim3(kBlock), 0, st, h->part_rz, g2, h->c.scal, h->p2p->dev, 1,
+                       slab_ar_tag(h->p2p, 1), (int)S_RZ);
+    hipLaunchKernelGGL(k_jac_begin_finish, dim3(1), dim3(64), 0, st, h->c.scal, h->c.hist);
+    MFS_LAUNCH_CHECK();
+    return MFS_OK;
+  }
   if (int e = core_begin_post(h->c, st, false)) return e;             // d = r = b - q, partials of r.r
   hipLaunchKernelGGL(k_slab_allreduce_rr, dim3(1), dim3(kBlock), 0, st, h->c.part_rr, h->c.n_part_rr, h->c.scal,
                      h->p2p->dev, 0, slab_ar_tag(h->p2p, 0));

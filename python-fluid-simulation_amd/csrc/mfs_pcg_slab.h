@@ -142,7 +142,7 @@ k_slab_edge_apply(const T* __restrict__ v, T* __restrict__ out, const T* __restr
 // k_slab_edge_apply (d.q) and of k_update_xr (r.r + bookkeeping).
 static __global__ void __launch_bounds__(kBlock)
 k_slab_allreduce_rr(const double* __restrict__ partial, int count, double* __restrict__ scal, P2pDev pd, int ring,
-                    unsigned tag) {
+                    unsigned tag, int which = S_RR) {
   double acc = 0.0;
   for (int i = threadIdx.x; i < count; i += kBlock) acc += partial[i];
   const double loc = block_sum<kBlock>(acc);          // thread 0
@@ -154,7 +154,7 @@ k_slab_allreduce_rr(const double* __restrict__ partial, int count, double* __res
   const double tot = slab_allreduce_wave(pd, ring, tag, s_loc, &ok);
   if (threadIdx.x != 0) return;
   if (!ok) { slab_fail(scal, 1); return; }
-  scal[S_RR] = tot;
+  scal[which] = tot;
 }
 
 }  // namespace mfs

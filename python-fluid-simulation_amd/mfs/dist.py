@@ -146,14 +146,6 @@ class SlabCG(_BoundedCollectives):
         if self.window is not None:
             ops.attach_p2p(self.window)
         self._bc_init()
-        # The opt-in Jacobi preconditioner is an extra of the single-GPU loop: the slab loops run the reference's
-        # unpreconditioned CG (same solution, the reference's iteration count).  Say so once instead of silently dropping
-        # to the collective loop with the flag ignored.
-        info = ops.loop_info() if hasattr(ops, "loop_info") else {}
-        if info.get("jacobi"):
-            warnings.warn("SlabCG: Jacobi preconditioning is a single-GPU extra -- the slab loop runs the reference's "
-                          "unpreconditioned CG (mfs_pcg3d_set_jacobi switched off on this engine)", RuntimeWarning, stacklevel=2)
-            ops.set_jacobi(False)
         self._p2p_active = None          # which loop the last begin() / solve() took (None: none yet)
         self.downgraded = ""             # why a given window is NOT being used (empty: it is, or none was given)
 
@@ -166,9 +158,20 @@ class SlabCG(_BoundedCollectives):
     def _note_downgrade(self):
         if self.window is not None and not self.downgraded:
             self.downgraded = ("the engine as bound cannot run the window loop (needs the fused direction update, "
-                               "the vector path, stencil variant 2, no Jacobi, matching plane size): collective loop")
+                               "the vector path, stencil variant 2, matching plane size): collective loop")
             warnings.warn(f"SlabCG rank {self.part.rank}: p2p window given but not usable -- {self.downgraded}",
                           RuntimeWarning, stacklevel=3)
+
+    def _drop_jacobi(self):
+        """The opt-in Jacobi preconditioner runs in the single-GPU loop and in the WINDOW slab loop; the collective loop is
+        the reference's unpreconditioned CG (same solution, the reference's iteration count).  Say so once and switch the
+        flag off instead of silently running phases that ignore it."""
+        info = self.ops.loop_info() if hasattr(self.ops, "loop_info") else {}
+        if info.get("jacobi"):
+            warnings.warn("SlabCG: the collective slab loop has no Jacobi preconditioning (the window loop and the single-GPU "
+                          "loop do) -- running the reference's unpreconditioned CG (mfs_pcg3d_set_jacobi switched off)",
+                          RuntimeWarning, stacklevel=3)
+            self.ops.set_jacobi(False)
 
     def _allreduce(self, slot):
         self._allreduce_bounded(self.ops.scalars[slot:slot + 1], f"all-reduce of CG scalar {slot}")
@@ -216,6 +219,7 @@ class SlabCG(_BoundedCollectives):
             self.ops.begin_local(tol)
             self.ops.begin_finish()
             return
+        self._drop_jacobi()
         self.ops.begin_local(tol)              # x = 0 everywhere, so q = A x needs no halo
         self._allreduce(_lib.S_RR)
         self.ops.begin_finish()
@@ -276,6 +280,7 @@ class SlabCG(_BoundedCollectives):
             self.multi = True                  # a window was given but cannot be used: the collective loop
         if not self.multi:
             return self.ops.solve(tol, max_iter, check_every)
+        self._drop_jacobi()
         self.begin(tol)
         self.drain()
         st = self.ops.poll()

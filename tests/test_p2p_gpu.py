@@ -183,3 +183,47 @@ def test_lost_peer_is_reported_not_hung(mode, extra, tmp_path):
     assert outcome.startswith("MfsError") and "status -4" in outcome and "timed out" in outcome, outcome
     assert float(secs) < 20.0
     assert mode_line == ("mode=rccl" if extra else "mode=p2p"), mode_line      # the downgrade is visible
+
+
+def _native_jacobi(g, dt):
+    gres = tuple(int(v) for v in g["gres"])
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+    eng = PcgEngine(gres, dt, DEV)
+    eng.setup(T(g["lphi"]), T(g["wx"]), T(g["wy"]), T(g["wz"]))
+    eng.set_jacobi(True)
+    b = T(g["b"]).to(dt)
+    x, d, r, q = (torch.zeros(gres, dtype=dt, device=DEV) for _ in range(4))
+    eng.bind(b, x, d, r, q)
+    ok, it = eng.solve(float(g["tol"]), int(np.prod(gres)), 16)
+    assert ok
+    return it, eng.history(), x.cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("name,world,dtname,defer", [
+    ("p3d_d_20", 1, "f64", "0"), ("p3d_d_20", 2, "f64", "0"), ("p3d_d_20", 3, "f64", "1"), ("p3d_d_20", 2, "f32", "0"),
+    ("p3d_a_12", 5, "f64", "1"),          # two owned planes per rank: no interior launch
+])
+def test_slab_p2p_jacobi(name, world, dtname, defer, tmp_path):
+    """the opt-in Jacobi loop through the window slab loop (z = r / diag as the operand of the edge and interior direction
+    updates, r.r AND r.z all-reduced in the tail of the r / z update) against the single-domain Jacobi solve"""
+    g = golden(name)
+    dt = torch.float64 if dtname == "f64" else torch.float32
+    it0, h0, x0 = _native_jacobi(g, dt)
+    assert it0 < int(g["iters"])            # it IS the preconditioned iteration
+    res = _run_ranks(name, world, tmp_path, dtname, solves=2 if world == 2 and dtname == "f64" else 1, MFS_JACOBI="1",
+                     MFS_DEFER_X=defer, MFS_SLAB_AUX_STREAM=defer)
+    gres = tuple(int(v) for v in g["gres"])
+    x = np.zeros(gres)
+    for r in res:
+        assert int(r["done"]) == 1
+        lo, hi = int(r["lo"]), int(r["hi"])
+        x[lo + 1:hi - 1] = r["x"][1:-1]
+    hists = [r["hist"] for r in res]
+    for h in hists[1:]:      # every rank took bit-identical scalars
+        np.testing.assert_array_equal(h, hists[0])
+    assert len({int(r["iters"]) for r in res}) == 1
+    h = hists[0]
+    n = min(21, len(h), len(h0))
+    np.testing.assert_allclose(h[:n], h0[:n], rtol=1e-10 if dtname == "f64" else 1e-5)
+    assert abs(int(res[0]["iters"]) - it0) <= max(2, it0 // 10)
+    np.testing.assert_allclose(x, x0, rtol=0, atol=(1e-4 if dtname == "f64" else 1e-3) * np.abs(x0).max())
