@@ -37,18 +37,20 @@
 #define MFS_VMARCH_MIN_WAVES 2     // waves per SIMD the kernel is compiled for (256 VGPRs)
 #endif
 
-// A/B knob (tools/build_variant.sh): wave priority around the fp64 row arithmetic.  1: rows run at raised priority (the
-// other wave of the SIMD gets the issue slots the rows leave: its LDS / vector-memory phases); 2: the reverse (memory
-// phases first).  0 (default): none.
+// Wave priority around the row arithmetic (MFS_VM_PRIO: A/B knob, tools/build_variant.sh).  2 (default, fp32 state): the
+// LDS / vector-memory phases of a step run at raised priority, the rows at base priority -- the two waves of a SIMD (one per
+// resident workgroup) then tend to sit in complementary phases instead of queueing for the same unit.  Same-box A/B
+// (profiles/r02_visc_prio_ab.txt), apply us per launch: 256^3 fp32 198.3 -> 192.3, 128^3 30.3 -> 29.3; fp64 state: 256^3 -1 %,
+// 128^3 +0.5 % (left off there).  1: the reverse (rows first): 256^3 fp32 194.4, 128^3 31.0.  0: none.
 #ifndef MFS_VM_PRIO
-#define MFS_VM_PRIO 0
+#define MFS_VM_PRIO 2
 #endif
 #if MFS_VM_PRIO == 1
-#define MFS_VM_ROWS_BEGIN() __builtin_amdgcn_s_setprio(2)
-#define MFS_VM_ROWS_END() __builtin_amdgcn_s_setprio(0)
+#define MFS_VM_ROWS_BEGIN() do { if (sizeof(T) == 4) __builtin_amdgcn_s_setprio(2); } while (0)
+#define MFS_VM_ROWS_END() do { if (sizeof(T) == 4) __builtin_amdgcn_s_setprio(0); } while (0)
 #elif MFS_VM_PRIO == 2
-#define MFS_VM_ROWS_BEGIN() __builtin_amdgcn_s_setprio(0)
-#define MFS_VM_ROWS_END() __builtin_amdgcn_s_setprio(2)
+#define MFS_VM_ROWS_BEGIN() do { if (sizeof(T) == 4) __builtin_amdgcn_s_setprio(0); } while (0)
+#define MFS_VM_ROWS_END() do { if (sizeof(T) == 4) __builtin_amdgcn_s_setprio(2); } while (0)
 #else
 #define MFS_VM_ROWS_BEGIN() do {} while (0)
 #define MFS_VM_ROWS_END() do {} while (0)
