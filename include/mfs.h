@@ -324,8 +324,14 @@ int mfs_vcg3d_finish(mfs_vcg3d* h, mfs_stream stream);
 /* 1 / 0: fused direction + x update in mfs_vcg3d_iterate / solve (default 0 -- measured slower, DESIGN.md section 4;
  * env MFS_VISC_FUSE); results bit-identical */
 int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on);
-/* bit 0: mfs_vcg3d_iterate will run the fused 2-launch loop for the engine as bound and set up */
+/* bit 0: mfs_vcg3d_iterate will run the fused 2-launch loop for the engine as bound and set up; bit 1: the small-problem
+ * loop -- the r update (:592-601), the r.r reduction, the test / bookkeeping (:604-608) and the x / direction updates
+ * (:595-597, :609-610) in ONE launch whose resident workgroups exchange their partial sums (csrc/mfs_cg_core.h
+ * k_update_rdx): 2 launches per iteration, results equal to the three-launch loop's up to the grouping of r.r */
 int mfs_vcg3d_loop_info(mfs_vcg3d* h);
+/* 1 / 0: allow that small-problem loop (default 1; env MFS_RDX).  A launch that is not fully resident (shared GPU) times
+ * out without having written anything; the next poll switches the engine to the three-launch loop for good. */
+int mfs_vcg3d_set_merged(mfs_vcg3d* h, int on);
 int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);
 int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every,

@@ -413,6 +413,176 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
   }, rev != 0);
 }
 
+// ---- small problems: the two vector phases of an iteration in ONE launch (k_update_rdx) -----------------------------
+// r -= alpha q ; r.r ; [test, beta] ; x += alpha d ; d = r + beta d  -- the r update, the reduction and the direction + x
+// update of k_update_xr<MODE 1> / k_update_d<XUPD>, with the r.r exchanged between the RESIDENT workgroups of the launch
+// instead of across a kernel boundary: every workgroup publishes its partial sum as a self-validating 16-byte record
+// {tag|lo, tag|hi} (agent scope, the granule scheme of mfs_p2p.h / mfs_pcg_resident.h), polls all of them and adds them in
+// one fixed order -- identical bits everywhere, no counter, no flag, no fence.  r_new stays in registers across the
+// exchange (one read of r less) and nothing is written before the total is known, so a launch whose workgroups are not
+// all resident (a GPU shared with other work) times out CLEAN: error word kErrNotResident, the poll switches the engine
+// back to the launch-per-phase loop and the iteration is redone.  One launch and one reduction tail less per iteration:
+// 48 x 80 x 48 fp64 viscosity 24.4 -> see DESIGN.md section 4.  Same arithmetic per element; the partial sums group by
+// kRdxW workgroups instead of the update kernel's grid, so results agree with the three-launch loop to rounding.
+constexpr int kRdxBlock = 512;
+constexpr int kRdxW = 128;                  // workgroups (all must be co-resident: 128 of 256 CUs)
+constexpr int kRdxMaxKV = 8;                // 16-byte vectors per thread held in registers
+typedef unsigned long long rdx_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rdx_u64x2 rdx_load2(const unsigned long long* p) {
+  rdx_u64x2 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+struct RdxArgs {
+  unsigned long long* rec;       // kRdxW records of two u64, kRdxRecStride u64 apart
+  unsigned tag;                  // != 0, unique per launch
+  unsigned long long timeout_ticks;   // wall clock, 100 MHz
+  int drop_block;                // fault injection (MFS_RDX_TEST_DROP_WG): this workgroup never publishes; -1 none
+  double* hist;
+  long long hist_cap;
+};
+constexpr int kRdxRecStride = 16;           // u64 words between records (128 bytes)
+
+template <typename T, int VEC, int KV>
+__global__ void __launch_bounds__(kRdxBlock)
+k_update_rdx(T* __restrict__ x, T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
+             double* __restrict__ scal, int par, const double* __restrict__ part_dq, int npart, RdxArgs a) {
+  typedef vec_t<T, VEC> V;
+  const double dn = scal[S_DONE];
+  const double delta = scal[S_RING + par], tol2 = scal[S_TOL2];
+  const int64_t nv = n / VEC;
+  const int64_t stride = (int64_t)kRdxW * kRdxBlock;
+  const int64_t k0 = (int64_t)blockIdx.x * kRdxBlock + threadIdx.x;
+  V rn[KV], qv[KV];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int64_t i = (k0 + k * stride) * VEC;
+    rn[k] = V{}; qv[k] = V{};
+    if (k0 + k * stride < nv) { rn[k] = vload<T, VEC>(r + i); qv[k] = vload<T, VEC>(q + i); }
+  }
+  const int64_t rest = n - nv * VEC;
+  const bool tail = blockIdx.x == 0 && (int64_t)threadIdx.x < rest;        // scalar tail (n % VEC elements)
+  const int64_t it_ = nv * VEC + threadIdx.x;
+  T rt = tail ? r[it_] : (T)0;
+  const T qt = tail ? q[it_] : (T)0;
+  // d.q: block_total_of's order (every workgroup: the same value)
+  double dq;
+  {
+    __shared__ double s_dq;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npart; i += kRdxBlock) acc += part_dq[i];
+    const double t = block_sum<kRdxBlock>(acc);
+    if (threadIdx.x == 0) s_dq = t;
+    __syncthreads();
+    dq = s_dq;
+  }
+  if (dn != 0.0) return;
+  const double alpha = delta / dq;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      rn[k][j] = (T)((double)rn[k][j] - alpha * (double)qv[k][j]);
+      acc += (double)rn[k][j] * (double)rn[k][j];          // (vectors past the end hold 0: they add nothing)
+    }
+  }
+  if (tail) { rt = (T)((double)rt - alpha * (double)qt); acc += (double)rt * (double)rt; }
+  // the operands of the second half, requested before the exchange (they are consumed after it)
+  V dv[KV], xv[KV];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int64_t i = (k0 + k * stride) * VEC;
+    dv[k] = V{}; xv[k] = V{};
+    if (k0 + k * stride < nv) { dv[k] = vload<T, VEC>(d + i); xv[k] = vload<T, VEC>(x + i); }
+  }
+  T dt_ = tail ? d[it_] : (T)0, xt = tail ? x[it_] : (T)0;
+  // ---- r.r over the launch: publish, poll, add in one fixed order
+  const double mine = block_sum<kRdxBlock>(acc);
+  if (threadIdx.x == 0 && (int)blockIdx.x != a.drop_block) {
+    unsigned long long* g = a.rec + (size_t)blockIdx.x * kRdxRecStride;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+    rdx_u64x2 w;
+    w[0] = ((unsigned long long)a.tag << 32) | (bits & 0xffffffffull);
+    w[1] = ((unsigned long long)a.tag << 32) | (bits >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(w) : "memory");
+  }
+  __shared__ double s_rr;
+  __shared__ int s_ok;
+  if (threadIdx.x < kWave) {
+    bool good = true;
+    double c[kRdxW / kWave];
+#pragma unroll
+    for (int m = 0; m < kRdxW / kWave; ++m) {
+      const unsigned long long* g = a.rec + (size_t)(m * kWave + threadIdx.x) * kRdxRecStride;
+      rdx_u64x2 w = rdx_load2(g);
+      bool got = (w[0] >> 32) == a.tag && (w[1] >> 32) == a.tag;
+      for (int spin = 0; spin < 64 && !got; ++spin) { w = rdx_load2(g); got = (w[0] >> 32) == a.tag && (w[1] >> 32) == a.tag; }
+      if (!got && good) {
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+          __builtin_amdgcn_s_sleep(1);
+          w = rdx_load2(g);
+          if ((w[0] >> 32) == a.tag && (w[1] >> 32) == a.tag) break;
+          if (wall_clock64() - t0 > a.timeout_ticks) { good = false; break; }
+        }
+      }
+      c[m] = __longlong_as_double((long long)((w[1] << 32) | (w[0] & 0xffffffffull)));
+    }
+    good = __all(good);
+    double tot = 0.0;
+#pragma unroll
+    for (int m = 0; m < kRdxW / kWave; ++m) tot += wave_sum(c[m]);      // records in index order, one fixed tree
+    if (threadIdx.x == 0) { s_rr = tot; s_ok = good ? 1 : 0; }
+  }
+  __syncthreads();
+  if (!s_ok) {       // not all workgroups are resident: nothing has been written; say so and stop the batch
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(scal + S_ERR, (double)kErrNotResident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(scal + S_DONE, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  const double rr = s_rr;
+  const bool conv = rr < tol2;
+  const double beta = rr / delta;
+  const int bad = cg_health(dq, rr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {      // k_update_d's bookkeeping
+    const int64_t it = (int64_t)scal[S_ITERS];
+    if (2 * it + 2 < a.hist_cap) { a.hist[2 * it + 1] = dq; a.hist[2 * it + 2] = rr; }
+    scal[S_ITERS] = (double)(it + 1);
+    scal[S_RING + (par ^ 1)] = rr;
+    scal[S_DQ] = dq;
+    scal[S_RR] = rr;
+    scal[S_DELTA] = delta;
+    scal[S_LASTRR] = rr;
+    scal[S_ALPHA] = alpha;
+    if (bad) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
+    else if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
+  }
+  // ---- second half: r (new), x += alpha d, and -- unless the iteration converged -- d = r + beta d   (:595-597, :604-610)
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int64_t i = (k0 + k * stride) * VEC;
+    if (k0 + k * stride < nv) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        xv[k][j] = (T)((double)xv[k][j] + alpha * (double)dv[k][j]);
+        dv[k][j] = (T)((double)rn[k][j] + beta * (double)dv[k][j]);
+      }
+      vstore<T, VEC>(r + i, rn[k]);
+      vstore<T, VEC>(x + i, xv[k]);
+      if (!conv && !bad) vstore<T, VEC>(d + i, dv[k]);
+    }
+  }
+  if (tail) {
+    r[it_] = rt;
+    x[it_] = (T)((double)xt + alpha * (double)dt_);
+    if (!conv && !bad) d[it_] = (T)((double)rt + beta * (double)dt_);
+  }
+}
+
 // d = r + beta d with beta as left in the scalar block by k_cg_book: the direction update a fused
 // native loop still owes when the host stops it WITHOUT convergence (the reference updates d at the
 // end of every non-converged iteration, :220-221)
@@ -519,11 +689,16 @@ struct CgCore {
   int xr_vpt = 8;  // vectors per thread the x/r update aims for on small problems (MFS_XR_VEC_PER_THREAD)
   int nt_x = -1;   // nontemporal x stream in k_update_xr: 1 on, 0 off, -1 auto (working set > Infinity Cache)
   double* pinned = nullptr;
+  // merged vector phases for small problems (k_update_rdx): records table, monotonic tag, on / off (MFS_RDX; switched off for
+  // good by a poll that finds the launch was not fully resident)
+  unsigned long long* rdx_rec = nullptr;
+  unsigned rdx_tag = 0;
+  int rdx = 1;
 };
 
 static inline size_t core_ws_bytes() {
   return 256 + align_up((size_t)kHistCap * 8, 256) + 2 * align_up((size_t)kMaxPartials * 8, 256) +
-         2 * align_up((size_t)kTicketWords * 4, 256);
+         2 * align_up((size_t)kTicketWords * 4, 256) + align_up((size_t)kRdxW * kRdxRecStride * 8, 256);
 }
 
 // carve scalars / history / partials out of the head of the workspace; returns the first free byte
@@ -533,6 +708,7 @@ static inline char* core_carve(CgCore& c, char* p) {
   c.part_dq = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
   c.part_rr = (double*)p; p += align_up((size_t)kMaxPartials * 8, 256);
   c.tickets = (unsigned*)p; p += 2 * align_up((size_t)kTicketWords * 4, 256);   // two ticket sets (zeroed with the workspace)
+  c.rdx_rec = (unsigned long long*)p; p += align_up((size_t)kRdxW * kRdxRecStride * 8, 256);   // zeroed too: tag 0 is never used
   return p;
 }
 
@@ -550,6 +726,7 @@ static inline int core_init(CgCore& c, int dt, int64_t n) {
   c.xr_vpt = std::max(1, env_int("MFS_XR_VEC_PER_THREAD", 8));
   c.rev_xr = env_int("MFS_REV_XR", 0);
   c.rev_d = env_int("MFS_REV_D", 0);
+  c.rdx = env_int("MFS_RDX", 1);
   if (hipHostMalloc((void**)&c.pinned, MFS_PCG_NSCALARS * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     set_error("hipHostMalloc for the poll buffer failed");
     return MFS_E_HIP;
@@ -671,6 +848,39 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
   }
   MFS_LAUNCH_CHECK();
   ++c.iter_enq;      // the d update closes an iteration
+  return MFS_OK;
+}
+
+// can the merged vector phases serve this engine?  (aligned vectors, everything in kRdxW workgroups' registers)
+static inline bool core_rdx_ok(const CgCore& c) {
+  if (!c.rdx || !c.x || !core_vec_ok(c)) return false;
+  const int64_t per = c.dt == MFS_F32 ? 4 : 2;
+  return c.n / per <= (int64_t)kRdxW * kRdxBlock * kRdxMaxKV && c.cus >= kRdxW;
+}
+
+// r update + r.r + bookkeeping + x / direction update of one iteration in one launch; closes the iteration
+static inline int core_update_rdx(CgCore& c, hipStream_t st) {
+  const int64_t per = c.dt == MFS_F32 ? 4 : 2;
+  const int64_t nv = c.n / per;
+  const int need = (int)((nv + (int64_t)kRdxW * kRdxBlock - 1) / ((int64_t)kRdxW * kRdxBlock));
+  if (c.rdx_tag >= 0xfffffff0u) {            // tags about to wrap: start over on a clean table
+    MFS_HIP_TRY(hipMemsetAsync(c.rdx_rec, 0, (size_t)kRdxW * kRdxRecStride * 8, st));
+    c.rdx_tag = 0;
+  }
+  RdxArgs a{c.rdx_rec, ++c.rdx_tag, (unsigned long long)std::max(1, env_int("MFS_RDX_TIMEOUT_MS", 250)) * 100000ull,
+            env_int("MFS_RDX_TEST_DROP_WG", -1), c.hist, kHistCap};
+  const int par = (int)(c.iter_enq & 1);
+#define MFS_RDX_GO(TT, VV, KK) \
+  hipLaunchKernelGGL((k_update_rdx<TT, VV, KK>), dim3(kRdxW), dim3(kRdxBlock), 0, st, (TT*)c.x, (TT*)c.d, (TT*)c.r, (const TT*)c.q, \
+                     c.n, c.scal, par, c.part_dq, c.n_part_dq, a)
+#define MFS_RDX_KV(TT, VV) \
+  do { if (need <= 1) MFS_RDX_GO(TT, VV, 1); else if (need <= 2) MFS_RDX_GO(TT, VV, 2); else if (need <= 4) MFS_RDX_GO(TT, VV, 4); \
+       else if (need <= 6) MFS_RDX_GO(TT, VV, 6); else MFS_RDX_GO(TT, VV, 8); } while (0)
+  if (c.dt == MFS_F32) MFS_RDX_KV(float, 4); else MFS_RDX_KV(double, 2);
+#undef MFS_RDX_KV
+#undef MFS_RDX_GO
+  MFS_LAUNCH_CHECK();
+  ++c.iter_enq;
   return MFS_OK;
 }
 

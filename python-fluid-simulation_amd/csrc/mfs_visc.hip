@@ -1477,10 +1477,17 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
     }
     return MFS_OK;
   }
+  // small problems: both vector phases, the r.r reduction and the bookkeeping in ONE launch whose workgroups exchange
+  // their partial sums while resident (k_update_rdx, mfs_cg_core.h): 2 launches per iteration, no reduction tail
+  const bool rdx = core_rdx_ok(h->c) && !h->p2p;
   for (int64_t i = 0; i < n; ++i) {
     int e, np = 0;
     if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;   // :589
     h->c.n_part_dq = np;
+    if (rdx) {
+      if ((e = core_update_rdx(h->c, st))) return e;                                  // :592-610
+      continue;
+    }
     if (h->split_x) {   // r -= alpha q here, x += alpha d rides in the direction update (8 instead of 9 scalars per DOF)
       if ((e = core_update_xr(h->c, true, st, 1))) return e;                          // :592-601 (r)
       if ((e = core_update_d(h->c, true, st, true))) return e;                        // :595-597 (x), :604-610
@@ -1516,7 +1523,19 @@ static int vcg_home(mfs_vcg3d* h, int64_t iters, bool converged, hipStream_t st)
 int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters, int* done, double* delta, double* alpha,
                    double* beta) {
   MFS_REQUIRE(h, "null handle");
-  return core_poll(h->c, (hipStream_t)stream, iters, done, delta, alpha, beta);
+  hipStream_t st = (hipStream_t)stream;
+  // The merged vector-phase launch did not get its workgroups together (a shared GPU): it -- and every launch queued behind
+  // it -- wrote nothing to the CG vectors, so the state is the one the scalar block describes.  Clear the flag, switch
+  // this engine to the launch-per-phase loop for good, and report the iterations that did complete.
+  MFS_HIP_TRY(hipMemcpyAsync(h->c.pinned, h->c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
+  MFS_HIP_TRY(hipStreamSynchronize(st));
+  if ((int)h->c.pinned[S_ERR] == kErrNotResident) {
+    MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_ERR, 0, sizeof(double), st));
+    MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_DONE, 0, sizeof(double), st));
+    h->c.rdx = 0;
+    h->c.iter_enq = (int64_t)h->c.pinned[S_ITERS];
+  }
+  return core_poll(h->c, st, iters, done, delta, alpha, beta);
 }
 
 int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every, mfs_stream stream,
@@ -1530,8 +1549,8 @@ int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   while (!done && enq < max_iter) {
     const int64_t n = std::min(check_every, max_iter - enq);
     if (int e = mfs_vcg3d_iterate(h, n, stream)) return e;
-    enq += n;
     if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+    enq = h->c.iter_enq;        // = enq + n, unless the poll has just taken a batch back (merged launch not resident)
   }
   if (int e = vcg_home(h, iters, done != 0, (hipStream_t)stream)) return e;
   if (iters_host) *iters_host = iters;
@@ -1560,7 +1579,14 @@ int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on) {
 // what mfs_vcg3d_iterate will do for the engine as bound: bit 0 fused direction + x update (2 launches per iteration)
 int mfs_vcg3d_loop_info(mfs_vcg3d* h) {
   if (!h || !h->c.x || !h->is_setup) return 0;
-  return vcg_fuse_ok(h) ? 1 : 0;
+  return (vcg_fuse_ok(h) ? 1 : 0) | ((!vcg_fuse_ok(h) && core_rdx_ok(h->c) && !h->p2p) ? 2 : 0);
+}
+
+// 1 / 0: the merged vector phases of small problems (k_update_rdx; default 1, env MFS_RDX)
+int mfs_vcg3d_set_merged(mfs_vcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->c.rdx = on ? 1 : 0;
+  return MFS_OK;
 }
 
 int64_t mfs_vcg3d_history(mfs_vcg3d* h, double* out_host, int64_t cap, mfs_stream stream) {

@@ -93,7 +93,12 @@ class VcgEngine:
 
     def loop_info(self):
         """{"fused": iterate() runs the 2-launch loop with the direction and x updates folded into the marching kernel}"""
-        return {"fused": bool(int(self.lib.mfs_vcg3d_loop_info(self.h)) & 1)}
+        b = int(self.lib.mfs_vcg3d_loop_info(self.h))
+        return {"fused": bool(b & 1), "merged_vector_phases": bool(b & 2)}
+
+    def set_merged(self, on):
+        """small problems: r update, r.r, bookkeeping and x / direction updates in one launch (default on)"""
+        _lib.check(self.lib.mfs_vcg3d_set_merged(self.h, int(bool(on))), "mfs_vcg3d_set_merged")
 
     # ---- slab decomposition (mfs/dist.py:SlabVCG): the phases of one iteration
     def set_slab(self, skip_top_x):
