@@ -275,10 +275,10 @@ __device__ __forceinline__ void vm_store(T* p, vec_t<T, VEC> o, bool first, bool
 // LDS: a ring of kVmRing plane slots (planes x-1, x, x+1 being read, x+2 being written), each the three components'
 // images [Nz halo | tile | Nz halo]
 constexpr int kVmRing = 4;
-template <int VEC>
-__host__ __device__ inline int vm_su(int Nz) { return 2 * Nz + kVmBlock * VEC; }
-template <typename T, int VEC>
-__host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing * 3 * vm_su<VEC>(Nz) * sizeof(T); }
+template <int VEC, int BLOCK = kVmBlock>
+__host__ __device__ inline int vm_su(int Nz) { return 2 * Nz + BLOCK * VEC; }
+template <typename T, int VEC, int BLOCK = kVmBlock>
+__host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing * 3 * vm_su<VEC, BLOCK>(Nz) * sizeof(T); }
 
 #define MFS_VM_PIN() __builtin_amdgcn_sched_barrier(0)
 // nontemporal hints (template NT; the host turns them on when the launch's working set exceeds the Infinity Cache, as the
@@ -336,8 +336,12 @@ struct VmFuse {
 };
 
 // slabs: the three boundary slabs (u at x = Nx-1, v at y = Ny-1, w at z = Nz-1) ride as extra blocks, as in k_vcg_apply_all
-template <typename T, int VEC, int WAVES, int NT, bool FUSE = false>
-__global__ void __launch_bounds__(kVmBlock, WAVES)
+// BLOCK: threads per workgroup = z-vectors per tile.  256 (two workgroups per CU) everywhere but fp64 state with rows so long
+// that the ring of a 256-vector tile -- two rows and two halo rows at Nz = 256 -- exceeds half the CU's LDS: there ONE
+// workgroup of 512 threads (a tile of four rows + two halo rows: the same eight waves per CU, 1.5x instead of 2x halo
+// traffic) replaces one of 256.
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock>
+__global__ void __launch_bounds__(BLOCK, WAVES)
 k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
                   int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
                   const double* __restrict__ done_flag, VmFuse<T> fz) {
@@ -359,7 +363,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       else if (b < g0 + g1) acc = vcg_slab_rows<T, 1, false>(c, k1, k2, v, oy, b1, b - g0, g1);
       else acc = vcg_slab_rows<T, 2, false>(c, k1, k2, v, oz, b2, b - g0 - g1, g2);
     }
-    const double tot = block_sum<kVmBlock>(acc);
+    const double tot = block_sum<BLOCK>(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
     return;
   }
@@ -369,7 +373,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   const int Nx = c.N[0], Ny = c.N[1], Nz = c.N[2], W1 = Nz + 1;
   const int nzv = Nz / VEC;
   const int ipp = (Ny - 2) * nzv;                          // interior z-vectors per plane
-  const int tiles = (ipp + kVmBlock - 1) / kVmBlock;
+  const int tiles = (ipp + BLOCK - 1) / BLOCK;
   const int np = Nx - 2;                                    // planes 1 .. Nx-2
   const int64_t total = (int64_t)tiles * np;
   const int G = gmain;
@@ -388,8 +392,8 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   const int64_t cs = (const T*)c.vol[2] - (const T*)c.vol[1];
   const unsigned char* const MP = c.msk;
   const int tid = threadIdx.x;
-  const int SU = vm_su<VEC>(Nz), BUF = 3 * SU;
-  const int tile_elems = kVmBlock * VEC;
+  const int SU = vm_su<VEC, BLOCK>(Nz), BUF = 3 * SU;
+  const int tile_elems = BLOCK * VEC;
 #ifdef MFS_VM_STAMPS
   unsigned long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -402,14 +406,14 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     const int len = (int)min((int64_t)(Nx - 1 - x0), s1 - i);
     const int x1 = x0 + len;
     i += len;
-    const int item_raw = tile * kVmBlock + tid;
+    const int item_raw = tile * BLOCK + tid;
     const bool active = item_raw < ipp;
     const int item = active ? item_raw : ipp - 1;           // clamp: inactive lanes load valid addresses
     const int yy = item / nzv, zv = item - yy * nzv;
     const bool first = zv == 0, last = zv == nzv - 1;
     const int y = yy + 1, z0 = zv * VEC;
     const int o_uv = y * Nz + z0, o_w = y * W1 + z0, o_c = y * c.pz + z0;   // in-plane offsets (u / v, w, class arrays)
-    const int tile_items = min(kVmBlock, ipp - tile * kVmBlock);
+    const int tile_items = min(BLOCK, ipp - tile * BLOCK);
     const int tile_len = tile_items * VEC;
     const int m0 = Nz + tile * tile_elems;                   // in-plane (u-layout) offset of the tile's first vector
     // LDS offset of this thread's vectors inside an image.  All three images use the u layout -- rows of Nz elements,
@@ -671,7 +675,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     for (int k = 0; k < 12; ++k) partial[4096 + (blockIdx.x * 4 + tid / 64) * 12 + k] = (double)stamp_sum[k];
   }
 #endif
-  const double tot = block_sum<kVmBlock>(acc);
+  const double tot = block_sum<BLOCK>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 

@@ -806,6 +806,19 @@ static int vslab_grid(const Box3& b) {
 // each, one beyond that -- measured at 256^3 fp32: one workgroup per CU runs within 7 % of two, the kernel is paced
 // by its instruction stream, not by occupancy)
 constexpr size_t kVmMaxLds = 152 * 1024;
+// threads per workgroup of the march for this engine: 256, or 512 where fp64 rows are so long that a 256-vector tile's ring
+// leaves room for only one workgroup per CU anyway (see k_vcg_apply_march, BLOCK)
+template <typename T, int VEC>
+static int vcg_march_block(const mfs_vcg3d* h) {
+  const int Nz = h->g.N[2];
+  const int knob = env_int("MFS_VISC_MARCH_BLOCK", 0);          // A/B: 256 / 512 forces, 0 auto
+  if (knob == 256) return 256;
+  const bool fits512 = vm_lds_bytes<T, VEC, 512>(Nz) <= 152 * 1024 && 2 * (Nz / VEC) <= 512;
+  if (knob == 512 && fits512) return 512;
+  if (sizeof(T) == 8 && vm_lds_bytes<T, VEC, 256>(Nz) > 80 * 1024 && fits512) return 512;
+  return 256;
+}
+
 template <typename T, int VEC = VecOf<T>::N>
 static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
@@ -817,29 +830,38 @@ static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
   return true;
 }
 
-template <typename T, int VEC, int WAVES, int NT, bool FUSE = false>
-static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
-                               int* nparts, const VmFuse<T>* fz = nullptr) {
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock>
+static int vcg_march_launch_blk(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
+                                int* nparts, const VmFuse<T>* fz) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
-  const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + kVmBlock - 1) / kVmBlock;
+  const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + BLOCK - 1) / BLOCK;
   const int64_t total = (int64_t)tiles * (Nx - 2);
-  const size_t lds = vm_lds_bytes<T, VEC>(Nz);
+  const size_t lds = vm_lds_bytes<T, VEC, BLOCK>(Nz);
   const int bpc = lds > 80 * 1024 ? 1 : h->march_bpc;
   const int gmain = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * bpc));
   const Box3 b0 = vslab_box(h, 0), b1 = vslab_box(h, 1), b2 = vslab_box(h, 2);
   const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
   static bool attr_set = false;        // per instantiation: more than the default 64 KB of dynamic LDS
   if (!attr_set) {
-    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kVmMaxLds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT, FUSE>), dim3(gmain + g0 + g1 + g2), dim3(kVmBlock), lds, st, h->cp, h->k1,
+  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK>), dim3(gmain + g0 + g1 + g2), dim3(BLOCK), lds, st, h->cp, h->k1,
                      h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial, done,
                      fz ? *fz : VmFuse<T>{});
   MFS_LAUNCH_CHECK();
   *nparts = gmain + g0 + g1 + g2;
   return MFS_OK;
+}
+
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false>
+static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
+                               int* nparts, const VmFuse<T>* fz = nullptr) {
+  if constexpr (VEC == VecOf<T>::N && WAVES == MFS_VMARCH_MIN_WAVES)
+    if (vcg_march_block<T, VEC>(h) == 512)
+      return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512>(h, vv, ob, partial, done, st, nparts, fz);
+  return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 256>(h, vv, ob, partial, done, st, nparts, fz);
 }
 
 template <typename T, int VEC, int WAVES>
