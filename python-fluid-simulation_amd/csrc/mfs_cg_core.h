@@ -939,10 +939,13 @@ static inline int core_begin_finish(CgCore& c, hipStream_t st) {
   return MFS_OK;
 }
 
+// have_pinned: the caller has just read the scalar block into c.pinned on this stream (and found nothing to repair)
 static inline int core_poll(CgCore& c, hipStream_t st, int64_t* iters, int* done, double* delta, double* alpha,
-                            double* beta) {
-  MFS_HIP_TRY(hipMemcpyAsync(c.pinned, c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
-  MFS_HIP_TRY(hipStreamSynchronize(st));
+                            double* beta, bool have_pinned = false) {
+  if (!have_pinned) {
+    MFS_HIP_TRY(hipMemcpyAsync(c.pinned, c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
+    MFS_HIP_TRY(hipStreamSynchronize(st));
+  }
   if (c.pinned[S_ERR] != 0.0) {
     const int code = (int)c.pinned[S_ERR];
     if (code == kErrZeroDq) {

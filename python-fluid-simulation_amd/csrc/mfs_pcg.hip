@@ -1051,13 +1051,15 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
   // from there.
   MFS_HIP_TRY(hipMemcpyAsync(h->c.pinned, h->c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
   MFS_HIP_TRY(hipStreamSynchronize(st));
+  bool fresh = true;
   if ((int)h->c.pinned[S_ERR] == kErrNotResident) {
     MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_ERR, 0, sizeof(double), st));
     MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_DONE, 0, sizeof(double), st));
     h->resident = 0;
     h->c.iter_enq = (int64_t)h->c.pinned[S_ITERS];
+    fresh = false;
   }
-  return core_poll(h->c, st, iters, done, delta, alpha, beta);
+  return core_poll(h->c, st, iters, done, delta, alpha, beta, fresh);
 }
 
 // what the native loop will do for the engine as bound: bit 0 fused direction update, bit 1 deferred x update, bit 2 Jacobi,

@@ -1551,13 +1551,15 @@ int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
   // this engine to the launch-per-phase loop for good, and report the iterations that did complete.
   MFS_HIP_TRY(hipMemcpyAsync(h->c.pinned, h->c.scal, MFS_PCG_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, st));
   MFS_HIP_TRY(hipStreamSynchronize(st));
+  bool fresh = true;
   if ((int)h->c.pinned[S_ERR] == kErrNotResident) {
     MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_ERR, 0, sizeof(double), st));
     MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_DONE, 0, sizeof(double), st));
     h->c.rdx = 0;
     h->c.iter_enq = (int64_t)h->c.pinned[S_ITERS];
+    fresh = false;
   }
-  return core_poll(h->c, st, iters, done, delta, alpha, beta);
+  return core_poll(h->c, st, iters, done, delta, alpha, beta, fresh);
 }
 
 int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every, mfs_stream stream,
