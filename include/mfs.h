@@ -329,6 +329,12 @@ int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on);
  * (:595-597, :609-610) in ONE launch whose resident workgroups exchange their partial sums (csrc/mfs_cg_core.h
  * k_update_rdx): 2 launches per iteration, results equal to the three-launch loop's up to the grouping of r.r */
 int mfs_vcg3d_loop_info(mfs_vcg3d* h);
+/* OPT-IN Jacobi preconditioning of the viscosity loop (default off; env MFS_VISC_JACOBI=1): z = r / diag with the operator's
+ * own diagonal (vol_c + scale mu (...), :268 / :338 / :408; built once per solve), delta = r.z, convergence test unchanged
+ * (r.r < tol^2).  NOT the reference's iteration (ViscosityCGSolver3D.py:575-612 is unpreconditioned): another residual
+ * history, the same solution to the tolerance, far fewer iterations where partly filled cells make the diagonal span orders
+ * of magnitude.  Single GPU (mfs_vcg3d_begin / iterate / solve); bit 2 of mfs_vcg3d_loop_info. */
+int mfs_vcg3d_set_jacobi(mfs_vcg3d* h, int on);
 /* 1 / 0: allow that small-problem loop (default 1; env MFS_RDX).  A launch that is not fully resident (shared GPU) times
  * out without having written anything; the next poll switches the engine to the three-launch loop for good. */
 int mfs_vcg3d_set_merged(mfs_vcg3d* h, int on);

@@ -1128,3 +1128,63 @@ def cg_jacobi(apply, diag, b, x, d, r, q, tol, max_iter, history=None):
         else:
             raise ValueError("Failed to converge!")
     return it, rr
+
+
+def visc_diag3d(gres, scale, mu, sphi, vol):
+    """the diagonal of the viscosity operator (`diag` of solver/ViscosityCGSolver3D.py:268, :338, :408) on the three
+    component arrays; 0 on solid and array-boundary faces.  (Operand of the build's opt-in Jacobi loop.)"""
+    sphi, vol = np.asarray(sphi, F64), np.asarray(vol, F64)
+    out = []
+    for axis in range(3):
+        d = np.zeros(_face_shape(gres, axis))
+        if min(d.shape) >= 3:
+            dg, comp, I = _row_views(gres, axis)
+            vs = {k: dg(vol, o) for k, o in _VOL_OFF.items()}
+            fR, fL, fT, fB, fF, fK = VISC_ROWS[axis]["diag"]
+            m = lambda f, a: a if f == 1 else f * a  # noqa: E731
+            diag = vs["c"] + scale * mu * (m(fR, vs["R"]) + m(fL, vs["L"]) + m(fT, vs["T"]) + m(fB, vs["B"])
+                                           + m(fF, vs["F"]) + m(fK, vs["K"]))
+            d[I] = np.where(dg(sphi, (0, 0, 0)) < 0, 0.0, diag)
+        out.append(d)
+    return out
+
+
+def visc_cg_jacobi(gres, scale, mu, B, X, sphi, vol, tol, max_iter, history=None):
+    """Jacobi-preconditioned restatement of the viscosity CG loop (solver/ViscosityCGSolver3D.py:575-612 with z = r / diag,
+    delta = r.z; the stopping rule stays sum(r.r) < tol^2 after the x / r update).  B, X: lists of the three component
+    arrays; X holds the initial guess and receives the solution.  history = [rr0, dq1, rr1, ...]."""
+    D = visc_diag3d(gres, scale, mu, sphi, vol)
+    shp = [b.shape for b in B]
+    zof = lambda R: [np.divide(r, d, out=np.zeros_like(r), where=d != 0) for r, d in zip(R, D)]  # noqa: E731
+    dot = lambda P, Q: sum(float(np.sum(p * q)) for p, q in zip(P, Q))  # noqa: E731
+    Q = [np.zeros(sh) for sh in shp]
+    visc_apply3d(gres, scale, mu, *X, *Q, sphi, vol)
+    R = [b - q for b, q in zip(B, Q)]
+    Dv = zof(R)
+    rr, delta = dot(R, R), dot(R, Dv)
+    if history is not None:
+        history.append(rr)
+    it = 0
+    if not rr < tol ** 2:
+        for it in range(1, int(max_iter) + 1):
+            for q in Q:
+                q[...] = 0.0
+            visc_apply3d(gres, scale, mu, *Dv, *Q, sphi, vol)
+            dq = dot(Dv, Q)
+            alpha = delta / dq
+            for x, d in zip(X, Dv):
+                x += alpha * d
+            for r, q in zip(R, Q):
+                r -= alpha * q
+            Z = zof(R)
+            rr, rz = dot(R, R), dot(R, Z)
+            if history is not None:
+                history.extend((dq, rr))
+            if rr < tol ** 2:
+                break
+            beta = rz / delta
+            delta = rz
+            Dv = [z + beta * d for z, d in zip(Z, Dv)]
+        else:
+            raise ValueError("Failed to converge!")
+    return it, rr

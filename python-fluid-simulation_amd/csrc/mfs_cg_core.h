@@ -672,6 +672,120 @@ static __global__ void k_begin_finish(double* scal, double* hist) {
 }
 
 
+// ------------------------------------------------- optional Jacobi preconditioning -----
+// NOT the reference's algorithm (its CG is unpreconditioned, SURVEY.md "three facts" 3): an opt-in extra
+// (mfs_pcg3d_set_jacobi, mfs_vcg3d_set_jacobi; generic over the flat CG vectors and a diagonal array) for callers that want fewer iterations and do not need the reference's residual
+// history.  z = r / diag is never stored: it is formed where it is consumed, so the preconditioner is fused
+// into the two vector phases (one extra read of `diag` each).  delta = r.z drives alpha and beta; the
+// convergence test stays the reference's r.r < tol^2.  Three launches per iteration: stencil, x/r update,
+// direction update; dot products folded into their consumers as in the plain loop.
+__device__ __forceinline__ double jac_z(double r, double dg) { return dg != 0.0 ? r / dg : 0.0; }
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_jac_init(const T* __restrict__ b, const T* __restrict__ q, const T* __restrict__ diag, T* __restrict__ d,
+           T* __restrict__ r, int64_t n, double* __restrict__ part_rr, double* __restrict__ part_rz) {
+  double arr = 0.0, arz = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const T rv = (T)((double)b[i] - (double)q[i]);
+    const double z = jac_z((double)rv, (double)diag[i]);
+    r[i] = rv;
+    d[i] = (T)z;
+    arr += (double)rv * (double)rv;
+    arz += (double)rv * z;
+  }
+  const double t1 = block_sum<kBlock>(arr);
+  const double t2 = block_sum<kBlock>(arz);
+  if (threadIdx.x == 0) { part_rr[blockIdx.x] = t1; part_rz[blockIdx.x] = t2; }
+}
+
+static __global__ void k_jac_begin_finish(double* scal, double* hist) {
+  if (threadIdx.x == 0) {
+    const double rr = scal[S_RR], rz = scal[S_RZ];
+    scal[S_DELTA] = rz;
+    scal[S_RING + 0] = rz;
+    scal[S_LASTRR] = rr;
+    hist[0] = rr;
+    if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0;
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_jac_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q,
+                const T* __restrict__ diag, int64_t n, double* __restrict__ scal, double* __restrict__ part_rr,
+                double* __restrict__ part_rz, int par, const double* __restrict__ part_dq, int npart) {
+  if (scal[S_DONE] != 0.0) return;
+  const double dq = block_total_of(part_dq, npart);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
+  const double alpha = scal[S_RING + par] / dq;
+  double arr = 0.0, arz = 0.0;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      vec_t<T, VEC> xv = vload<T, VEC>(x + i), rv = vload<T, VEC>(r + i);
+      const vec_t<T, VEC> dv = vload<T, VEC>(d + i), qv = vload<T, VEC>(q + i), gv = vload<T, VEC>(diag + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
+        rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
+        arr += (double)rv[j] * (double)rv[j];
+        arz += (double)rv[j] * jac_z((double)rv[j], (double)gv[j]);
+      }
+      vstore<T, VEC>(x + i, xv);
+      vstore<T, VEC>(r + i, rv);
+    } else {
+      x[i] = (T)((double)x[i] + alpha * (double)d[i]);
+      const T rn = (T)((double)r[i] - alpha * (double)q[i]);
+      r[i] = rn;
+      arr += (double)rn * (double)rn;
+      arz += (double)rn * jac_z((double)rn, (double)diag[i]);
+    }
+  });
+  const double t1 = block_sum<kBlock>(arr);
+  const double t2 = block_sum<kBlock>(arz);
+  if (threadIdx.x == 0) { part_rr[blockIdx.x] = t1; part_rz[blockIdx.x] = t2; }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__ diag, int64_t n,
+               double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
+               const double* __restrict__ part_rr, const double* __restrict__ part_rz, int npart) {
+  if (scal[S_DONE] != 0.0) return;
+  const double rr = block_total_of(part_rr, npart);
+  const double rz = block_total_of(part_rz, npart);
+  const double delta = scal[S_RING + par];
+  const bool conv = rr < scal[S_TOL2];
+  const double beta = rz / delta;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double dq = scal[S_DQ];
+    const int64_t it = (int64_t)scal[S_ITERS];
+    if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
+    scal[S_ITERS] = (double)(it + 1);
+    scal[S_RING + (par ^ 1)] = rz;
+    scal[S_RR] = rr;
+    scal[S_RZ] = rz;
+    scal[S_DELTA] = delta;
+    scal[S_LASTRR] = rr;
+    scal[S_ALPHA] = delta / dq;
+    if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
+    else if (conv) scal[S_DONE] = 1.0; else scal[S_BETA] = beta;
+  }
+  if (conv) return;
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) {
+      vec_t<T, VEC> dv = vload<T, VEC>(d + i);
+      const vec_t<T, VEC> rv = vload<T, VEC>(r + i), gv = vload<T, VEC>(diag + i);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dv[j] = (T)(jac_z((double)rv[j], (double)gv[j]) + beta * (double)dv[j]);
+      vstore<T, VEC>(d + i, dv);
+    } else {
+      d[i] = (T)(jac_z((double)r[i], (double)diag[i]) + beta * (double)d[i]);
+    }
+  });
+}
+
 // ------------------------------------------------------------- host side ----
 // The flat CG state of one engine: n DOFs of dtype dt in five caller-owned vectors.
 struct CgCore {

@@ -380,6 +380,38 @@ __device__ __forceinline__ double vcg_row(const Compact& c, double k1, double k2
   return vcg_row_s<AXIS, MASK>(smp, k1, k2, own_ok, own_out);
 }
 
+// The diagonal of the operator on the flat [u | v | w] layout (opt-in Jacobi loop): vcg_row_n's own expression
+// diag = vol_c + k (fR R + fL L + fT T + fB B + fF F + fK K) (:268, :338, :408) on interior non-solid faces, 0 elsewhere.
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(256) k_vcg_diag(Compact c, double k1, T* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int s0 = c.N[0] + (AXIS == 0), s1 = c.N[1] + (AXIS == 1), s2 = c.N[2] + (AXIS == 2);
+  const int64_t n = (int64_t)s0 * s1 * s2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int z = (int)(i % s2), y = (int)((i / s2) % s1), x = (int)(i / ((int64_t)s2 * s1));
+  double dg = 0.0;
+  const bool interior = x > 0 && x < s0 - 1 && y > 0 && y < s1 - 1 && z > 0 && z < s2 - 1;
+  if (interior && ((c.msk[c.idx(x, y, z)] >> AXIS) & 1) != 0) {
+    double vs[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int ax = kD0[AXIS][0] + kVolOff[k][0], ay = kD0[AXIS][1] + kVolOff[k][1], az = kD0[AXIS][2] + kVolOff[k][2];
+      const int p = ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1);
+      vs[k] = (double)((const T*)c.vol[p])[c.idx(x + fdiv2(ax), y + fdiv2(ay), z + fdiv2(az))];
+    }
+    double sm = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const bool two = kDiagFac[AXIS][k] == 2;
+      if (k == 0) sm = two ? 2 * vs[1] : vs[1];
+      else sm = two ? __builtin_fma(2.0, vs[k + 1], sm) : sm + vs[k + 1];
+    }
+    dg = __builtin_fma(k1, sm, vs[0]);
+  }
+  out[i] = (T)dg;
+}
+
 // rows of ONE component over a box of faces (used for the three boundary slabs the
 // fused kernel does not cover, and as the simple reference form)
 template <typename T, int AXIS, bool MASK>
@@ -740,6 +772,10 @@ struct mfs_vcg3d {
   int march_bpc;   // its workgroups per CU (2: what its register budget makes resident)
   int march_vec;   // experiment: 2 = 8-byte vectors for fp32 state
   mfs_p2p* p2p;    // window transport of the slab loop (mfs_vcg3d_attach_p2p); null: the caller moves halos / scalars
+  int jacobi;      // 1: opt-in Jacobi-preconditioned loop (mfs_vcg3d_set_jacobi; NOT the reference's iteration)
+  void* diag;      // its diagonal (n elements, built by setup when the flag is on)
+  double* part_rz; // its r.z partials
+  bool diag_ready;
   int fuse;        // 1: mfs_vcg3d_iterate / solve fold the direction and x updates into the march (2 launches per iteration); default 0
   void* d2;        // ping-pong partner of the bound d for that loop (n elements, zero outside the faces the loop writes)
   bool fused_run;  // the fused loop has run since begin: x lags by one update, d_j may sit in d2 (vcg_home settles both)
@@ -1248,6 +1284,23 @@ int mfs_visc_writeback3d(const int64_t gres[3], void* vx, void* vy, void* vz, in
   return MFS_OK;
 }
 
+}  // extern "C"
+
+// the operator's diagonal on the flat layout (once per solve, Jacobi loop only)
+static int vcg_build_diag(mfs_vcg3d* h, hipStream_t st) {
+  if (h->diag_ready) return MFS_OK;
+#define MFS_VDIAG(TT, AX) \
+  hipLaunchKernelGGL((k_vcg_diag<TT, AX>), dim3(cdiv(h->nf[AX], 256)), dim3(256), 0, st, h->cp, h->k1, (TT*)h->diag + h->off[AX])
+  if (h->dt == MFS_F32) { MFS_VDIAG(float, 0); MFS_VDIAG(float, 1); MFS_VDIAG(float, 2); }
+  else                  { MFS_VDIAG(double, 0); MFS_VDIAG(double, 1); MFS_VDIAG(double, 2); }
+#undef MFS_VDIAG
+  MFS_LAUNCH_CHECK();
+  h->diag_ready = true;
+  return MFS_OK;
+}
+
+extern "C" {
+
 // ------------------------------------------------------------------ engine ---
 size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
@@ -1255,6 +1308,8 @@ size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   for (int p = 1; p < 8; ++p) tot += class_stride_bytes(gres, dt);
   tot += align_up((size_t)class_count(gres, 0), 4096);       // the packed mask bytes
   tot += align_up((size_t)mfs_vcg3d_dofs(gres) * dtype_size(dt), 4096);   // partner of d (fused loop)
+  tot += align_up((size_t)mfs_vcg3d_dofs(gres) * dtype_size(dt), 4096);   // diagonal (Jacobi loop)
+  tot += align_up((size_t)kMaxPartials * 8, 4096);                        // r.z partials (Jacobi loop)
   return tot;
 }
 
@@ -1287,6 +1342,10 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   for (int q = 1; q < 8; ++q) { h->cp.vol[q] = p; p += class_stride_bytes(gres, dt); }
   h->cp.msk = (unsigned char*)p; p += align_up((size_t)class_count(gres, 0), 4096);
   h->d2 = p; p += align_up((size_t)h->n * dtype_size(dt), 4096);
+  h->diag = p; p += align_up((size_t)h->n * dtype_size(dt), 4096);
+  h->part_rz = (double*)p; p += align_up((size_t)kMaxPartials * 8, 4096);
+  h->jacobi = env_int("MFS_VISC_JACOBI", 0);
+  h->diag_ready = false;
   h->fuse = env_int("MFS_VISC_FUSE", 0);   // measured slower than the three-launch loop: opt-in
   h->fused_run = false;
   h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
@@ -1341,7 +1400,8 @@ int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int
   h->k1 = scale * mu;          // `scale * mu * ...`      (left to right, as the reference evaluates it)
   h->k2 = 2 * scale * mu;      // `2 * scale * mu * ...`
   h->is_setup = true;
-  return MFS_OK;
+  h->diag_ready = false;
+  return h->jacobi ? vcg_build_diag(h, (hipStream_t)stream) : MFS_OK;
 }
 
 int mfs_vcg3d_apply(mfs_vcg3d* h, const void* v, void* out, mfs_stream stream) {
@@ -1375,6 +1435,22 @@ int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;     // x keeps the extrapolated velocity (:569-573)
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;   // :575
+  if (h->jacobi) {       // opt-in: r = b - q, d = z = r / diag, delta0 = r.z (stopping rule stays r.r < tol^2)
+    if (int e = vcg_build_diag(h, st)) return e;
+    const int g2 = std::max(1, (int)std::min<int64_t>(h->c.grid_vec, (h->n + kBlock - 1) / kBlock));
+    if (h->dt == MFS_F32)
+      hipLaunchKernelGGL((k_jac_init<float>), dim3(g2), dim3(kBlock), 0, st, (const float*)h->c.b, (const float*)h->c.q,
+                         (const float*)h->diag, (float*)h->c.d, (float*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+    else
+      hipLaunchKernelGGL((k_jac_init<double>), dim3(g2), dim3(kBlock), 0, st, (const double*)h->c.b, (const double*)h->c.q,
+                         (const double*)h->diag, (double*)h->c.d, (double*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+    h->c.n_part_rr = g2;
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st, h->c.part_rr, g2, h->c.scal, (int)S_RR, 0);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st, h->part_rz, g2, h->c.scal, (int)S_RZ, 0);
+    hipLaunchKernelGGL(k_jac_begin_finish, dim3(1), dim3(64), 0, st, h->c.scal, h->c.hist);
+    MFS_LAUNCH_CHECK();
+    return MFS_OK;
+  }
   if (int e = core_begin_post(h->c, st)) return e;                // :577-585
   return core_begin_finish(h->c, st);
 }
@@ -1468,13 +1544,46 @@ int mfs_vcg3d_slab_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
 
 // can the fused loop serve the engine as bound?  (the marching kernel's preconditions, 16-byte aligned CG vectors)
 static bool vcg_fuse_ok(const mfs_vcg3d* h) {
-  if (!h->fuse || !h->split_x || h->mask_cg || h->tiled || h->march_vec == 2 || !h->c.d || !core_vec_ok(h->c)) return false;
+  if (!h->fuse || h->jacobi || !h->split_x || h->mask_cg || h->tiled || h->march_vec == 2 || !h->c.d || !core_vec_ok(h->c)) return false;
   return h->dt == MFS_F32 ? vcg_march_ok<float>(h, h->c.d, h->c.q) : vcg_march_ok<double>(h, h->c.d, h->c.q);
 }
+
+extern "C++" {
+// one iteration of the opt-in Jacobi loop: stencil launch, x / r update with r.r and r.z (z = r / diag formed on the fly),
+// direction update d = z + beta d with the bookkeeping -- the generic kernels of mfs_cg_core.h on the flat vectors
+template <typename T, int VEC>
+static int vcg_jac_iteration(mfs_vcg3d* h, hipStream_t st) {
+  int e, np = 0;
+  if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, false, st, &np))) return e;
+  h->c.n_part_dq = np;
+  const int grid = core_vec_grid(h->c, VEC > 1);
+  const int par = (int)(h->c.iter_enq & 1);
+  hipLaunchKernelGGL((k_jac_update_xr<T, VEC>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)h->c.d, (T*)h->c.r,
+                     (const T*)h->c.q, (const T*)h->diag, h->n, h->c.scal, h->c.part_rr, h->part_rz, par, h->c.part_dq,
+                     h->c.n_part_dq);
+  hipLaunchKernelGGL((k_jac_update_d<T, VEC>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.d, (const T*)h->c.r,
+                     (const T*)h->diag, h->n, h->c.scal, h->c.hist, kHistCap, par, h->c.part_rr, h->part_rz, grid);
+  MFS_LAUNCH_CHECK();
+  h->c.n_part_rr = grid;
+  ++h->c.iter_enq;
+  return MFS_OK;
+}
+}  // extern "C++"
 
 int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
+  if (h->jacobi) {
+    MFS_REQUIRE(h->diag_ready, "Jacobi loop: mfs_vcg3d_begin has not built the diagonal");
+    const bool vec = core_vec_ok(h->c);
+    for (int64_t i = 0; i < n; ++i) {
+      int e;
+      if (h->dt == MFS_F32) e = vec ? vcg_jac_iteration<float, 4>(h, st) : vcg_jac_iteration<float, 1>(h, st);
+      else e = vec ? vcg_jac_iteration<double, 2>(h, st) : vcg_jac_iteration<double, 1>(h, st);
+      if (e) return e;
+    }
+    return MFS_OK;
+  }
   if (vcg_fuse_ok(h)) {
     // Fused loop, 2 launches per iteration:  A | R   A* | R   A* | R ...   A = plain march (iteration 0: d_0 = r_0 is there),
     // A* = march that first forms d_j = r + beta d_{j-1} (into the other buffer of {bound d, d2}) and lets x += alpha d_{j-1}
@@ -1602,8 +1711,16 @@ int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on) {
 
 // what mfs_vcg3d_iterate will do for the engine as bound: bit 0 fused direction + x update (2 launches per iteration)
 int mfs_vcg3d_loop_info(mfs_vcg3d* h) {
-  if (!h || !h->c.x || !h->is_setup) return 0;
-  return (vcg_fuse_ok(h) ? 1 : 0) | ((!vcg_fuse_ok(h) && core_rdx_ok(h->c) && !h->p2p) ? 2 : 0);
+  if (!h) return 0;
+  if (!h->c.x || !h->is_setup) return h->jacobi ? 4 : 0;
+  return (vcg_fuse_ok(h) ? 1 : 0) | ((!h->jacobi && !vcg_fuse_ok(h) && core_rdx_ok(h->c) && !h->p2p) ? 2 : 0) | (h->jacobi ? 4 : 0);
+}
+
+// OPT-IN Jacobi preconditioning of mfs_vcg3d_begin / iterate / solve (default off; env MFS_VISC_JACOBI=1): see mfs.h
+int mfs_vcg3d_set_jacobi(mfs_vcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->jacobi = on ? 1 : 0;
+  return MFS_OK;
 }
 
 // 1 / 0: the merged vector phases of small problems (k_update_rdx; default 1, env MFS_RDX)

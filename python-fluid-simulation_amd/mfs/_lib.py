@@ -131,6 +131,7 @@ SIGNATURES = {
     "mfs_vcg3d_set_fuse": (_i, [_p, _i]),
     "mfs_vcg3d_loop_info": (_i, [_p]),
     "mfs_vcg3d_set_merged": (_i, [_p, _i]),
+    "mfs_vcg3d_set_jacobi": (_i, [_p, _i]),
     "mfs_vcg3d_history": (_i64, [_p, _pd, _i64, _p]),
     "mfs_vcg3d_apply_kernel": (_i, [_p]),
     "mfs_vcg3d_set_slab": (_i, [_p, _i]),

@@ -94,7 +94,12 @@ class VcgEngine:
     def loop_info(self):
         """{"fused": iterate() runs the 2-launch loop with the direction and x updates folded into the marching kernel}"""
         b = int(self.lib.mfs_vcg3d_loop_info(self.h))
-        return {"fused": bool(b & 1), "merged_vector_phases": bool(b & 2)}
+        return {"fused": bool(b & 1), "merged_vector_phases": bool(b & 2), "jacobi": bool(b & 4)}
+
+    def set_jacobi(self, on):
+        """opt-in Jacobi preconditioning (NOT the reference's CG: fewer iterations, another residual history); takes effect
+        at the next setup()"""
+        _lib.check(self.lib.mfs_vcg3d_set_jacobi(self.h, int(bool(on))), "mfs_vcg3d_set_jacobi")
 
     def set_merged(self, on):
         """small problems: r update, r.r, bookkeeping and x / direction updates in one launch (default on)"""

@@ -82,7 +82,10 @@ class ViscosityCGSolver3D:
     Extras: `iterations`, `history`; `precision` / MFS_PRECISION selects fp32 state.
     """
 
-    def __init__(self, gres, bound_size, precision=None, device=None, check_every=32):
+    def __init__(self, gres, bound_size, precision=None, device=None, check_every=32, jacobi=None):
+        """`jacobi=True` (or MFS_VISC_JACOBI=1) switches on the build's opt-in Jacobi preconditioner: far fewer iterations
+        where partly filled cells make the operator's diagonal span orders of magnitude, the same solution to `tol`, but
+        NOT the reference's residual history (its CG is unpreconditioned, :575-612)."""
         self.gres = gres
         self._g = T.as_gres(gres)
         if len(self._g) != 3:
@@ -92,6 +95,8 @@ class ViscosityCGSolver3D:
         dt = T.state_dtype(precision)
         device = torch.device("cuda" if device is None else device)
         self._engine = VcgEngine(self._g, dt, device)
+        if jacobi is not None:
+            self._engine.set_jacobi(jacobi)
         self.vol = torch.zeros(T.doubled_shape(self._g), dtype=torch.float64, device=device)
         self._flat = {}
         for nm in "drqxb":
