@@ -345,6 +345,31 @@ def viscosity_leg(torch, dev, n, steps, with_parity):
     return out
 
 
+def viscosity_jacobi_leg(torch, dev, n):
+    """the OPT-IN Jacobi-preconditioned viscosity loop on BASELINE config 3's scene (fp32 state, the reference's default
+    tol = 1e-3): iterations and time of a whole solve() against the reference's unpreconditioned CG"""
+    from mfs import scenes
+    import solver.ViscosityCGSolver3D as V
+    gres = (n, n, n)
+    sc = scenes.viscosity_scene_3d(gres, seed=3, device=dev)
+    out = {"workload": f"ViscosityCGSolver3D {n}^3 buckling-like scene, fp32 state, tol 1e-3, mu {sc['mu']}"}
+    for jac in (False, True):
+        s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision="fp32", device=dev, jacobi=jac)
+        for rep in range(2):          # first solve: allocations / first launches
+            vx, vy, vz = sc["vx"].clone(), sc["vy"].clone(), sc["vz"].clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s.solve(sc["dt"], sc["mu"], sc["rho"], vx, vy, vz, sc["sphi"], sc["sv"], sc["lphi"], sc["lvol"], tol=1e-3)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+        out["jacobi" if jac else "reference_cg"] = {"iterations": int(s.iterations), "solve_ms": round(ms, 2)}
+        del s
+    out["note"] = ("opt-in (jacobi=True / MFS_VISC_JACOBI=1), off by default: not the reference's residual history; stopped by the "
+                   "same rule, its iterate is CLOSER to the exact solution than the reference's (tests/test_viscosity_jacobi_gpu.py)")
+    torch.cuda.empty_cache()
+    return out
+
+
 def jacobi_leg(args, torch, dev, tdt, lgres, seed):
     """the OPT-IN Jacobi-preconditioned loop (north_star: "Jacobi-precondition fused"; NOT the reference's iteration) on the
     bench workload: time per iteration of the fused two-launch form, and what it buys -- iterations and time of a whole
@@ -743,6 +768,7 @@ def main():
             visc_line = {"config3_128": viscosity_leg(torch, dev, 128, 200, True),
                          "n256": viscosity_leg(torch, dev, 256, 60, False)}
             jac_line = jacobi_leg(args, torch, dev, tdt, lgres, seed)
+            jac_line["viscosity"] = viscosity_jacobi_leg(torch, dev, 128)
     if world > 1:
         dist.barrier()
 

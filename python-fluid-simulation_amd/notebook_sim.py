@@ -42,7 +42,9 @@ class NotebookSimulation:
     px: (P,3) float64 particle positions; pdx: particle spacing (mass = rho * pdx^3, volume = pdx^3)."""
 
     def __init__(self, gres, gdx, bound_min, rb_d, px, pdx, rho=1000.0, mu=1.0, dt=1.0 / 300.0, device="cuda",
-                 precision=None):
+                 precision=None, jacobi=False):
+        """jacobi=True: the build's opt-in Jacobi preconditioning for the viscosity and pressure solves (NOT the reference's
+        iterations -- same stopping rules, a fraction of the CG iterations; single-GPU class only)"""
         dev = torch.device(device)
         g = tuple(int(v) for v in gres)
         self.GRES, self.GDX, self.PDX, self.RHO, self.MU, self.DT = g, float(gdx), float(pdx), float(rho), float(mu), float(dt)
@@ -78,6 +80,7 @@ class NotebookSimulation:
         self.fluid_volume = NS(resolution=dres, bound_size=bsz, bound_min=bmin, cell_size=dcs,
                                vol=torch.zeros(dres, dtype=torch.float64, device=dev))
         self._precision = precision
+        self._jacobi = bool(jacobi)
         self._make_solvers()
         self.current_time = 0.0
         self.iterations = 0
@@ -89,6 +92,10 @@ class NotebookSimulation:
         self.PressureSolver = PressureCGSolver3D(self.CGBuf, g, self.GDX)
         self.DensitySolver = DensityCGSolver3D(self.CGBuf, g, self.BOUND_MIN, self.BOUND_SIZE)
         self.ViscositySolver = ViscosityCGSolver3D(g, self.BOUND_SIZE, precision=self._precision, device=dev)
+        if getattr(self, "_jacobi", False):
+            self.PressureSolver._engine.set_jacobi(True)
+            self.ViscositySolver._engine.set_jacobi(True)
+            self.DensitySolver._engine.set_jacobi(True)      # (the pressure engine with the density operator's -z tap)
 
     def _solve_grid(self, dt, tick, t):
         """the two hot-path solves of the loop body (ipynb:4623, 4648) on the grid velocities, in place"""

@@ -39,7 +39,8 @@ rng = np.random.default_rng(0)
 t0 = time.perf_counter()
 px = NSIM.add_box([0.0, 0.7, 0.0], [0.5, 0.5, 0.5], gdx / 2, rng)
 if dist is None:
-    sim = NSIM.NotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"))
+    sim = NSIM.NotebookSimulation((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"),
+                                  jacobi=os.environ.get("MFS_TIMESTEP_JACOBI", "0") == "1")
 else:
     # MFS_TIMESTEP_PARTICLES=replicated: the round-1 form (every rank holds all particles, whole-grid broadcasts)
     cls = NSIM.SlabNotebookSimulation if os.environ.get("MFS_TIMESTEP_PARTICLES") == "replicated" else NSIM.ShardedNotebookSimulation

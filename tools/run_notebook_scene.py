@@ -28,7 +28,8 @@ def oob_filter(px):
 
 
 px = NSIM.add_box([0.0, 0.65, 0.0], [0.3, 0.3, 0.3], PDX, np.random.default_rng(0), keep=oob_filter)
-sim = NSIM.NotebookSimulation((48, 80, 48), GDX, [-0.3, 0, -0.3], rb_d, px, PDX, rho=1000, mu=1.0, dt=1 / 300, device=dev)
+JAC = len(sys.argv) > 2 and sys.argv[2] == "jacobi"      # usage: run_notebook_scene.py [steps] [jacobi]
+sim = NSIM.NotebookSimulation((48, 80, 48), GDX, [-0.3, 0, -0.3], rb_d, px, PDX, rho=1000, mu=1.0, dt=1 / 300, device=dev, jacobi=JAC)
 sim.step()
 tim, its = {}, []
 t0 = time.perf_counter()
