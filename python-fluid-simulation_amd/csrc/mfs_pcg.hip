@@ -68,104 +68,7 @@ k_pcg_setup(int Nx, int Ny, int Nz, const void* lphi, int ldt, const void* wx, c
 // (the three-launch Jacobi kernels -- jac_z, k_jac_init, k_jac_begin_finish, k_jac_update_xr, k_jac_update_d -- live in
 // mfs_cg_core.h: the viscosity engine uses them too)
 
-// ---- the FUSED Jacobi loop (2 launches + a one-block bookkeeping launch per iteration): z = r / diag is STORED by the
-// r update -- which reads diag anyway for r.z -- into an engine buffer, and the stencil launch of the next iteration forms
-// d = z + beta d_old on the fly with the plain loop's fused kernel (k_pcg_apply_march FUSE, operand `r` := z), the
-// deferred x update riding along as there.  12 + 2 scalars per cell and iteration instead of 6 + 8 + 5 in three full passes.
-// XUPD: x += alpha d here (cache-resident sizes); otherwise the next stencil launch does it (XDEF).
-// cls (compressed coefficient access on): the class byte of a z-vector stands for its diagonal unless the vector is MIXED
-// (ZERO: 0 -> z = 0; REGULAR: 6; a class leaves the never-computed boundary cells of a vector open, where r is exactly 0 and
-// z therefore 0 either way).  The LAST block to finish closes the iteration (last_block_total2 + jac_book): no third launch.
-// (dq comes as a VALUE: scal[S_DQ] is a plain store of another workgroup of the same launch, possibly behind another XCD's L2)
-__device__ __forceinline__ void jac_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
-                                         double dq, double rr, double rz) {
-  const double delta = scal[S_RING + par];
-  const int64_t it = (int64_t)scal[S_ITERS];
-  if (2 * it + 2 < hist_cap) { hist[2 * it + 1] = dq; hist[2 * it + 2] = rr; }
-  scal[S_ITERS] = (double)(it + 1);
-  scal[S_RING + (par ^ 1)] = rz;
-  scal[S_RR] = rr;
-  scal[S_RZ] = rz;
-  scal[S_DELTA] = delta;
-  scal[S_LASTRR] = rr;
-  scal[S_ALPHA] = delta / dq;
-  if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
-  else if (rr < scal[S_TOL2]) scal[S_DONE] = 1.0; else scal[S_BETA] = rz / delta;
-}
-
-struct JacSlab { int on; P2pDev pd; int ring[2]; unsigned tag[2]; };
-
-template <typename T, int VEC, bool XUPD>
-__global__ void __launch_bounds__(kBlock)
-k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q,
-                const T* __restrict__ diag, T* __restrict__ z, int64_t n, double* __restrict__ scal,
-                double* __restrict__ part_rr, double* __restrict__ part_rz, int par, const double* __restrict__ part_dq,
-                int npart, const unsigned char* __restrict__ cls, double* __restrict__ hist, int64_t hist_cap,
-                unsigned* __restrict__ ticket, JacSlab sl) {
-  const double dn = scal[S_DONE];
-  const double delta = scal[S_RING + par];
-  // d.q: folded from the stencil launch's partials (one GPU) or the all-reduced scalar (slab loop: npart == 0)
-  const double dq = npart > 0 ? block_total_of(part_dq, npart) : scal[S_DQ];
-  if (dn != 0.0) return;
-  if (npart > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
-  const double alpha = delta / dq;
-  double arr = 0.0, arz = 0.0;
-  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
-    if (vec) {
-      vec_t<T, VEC> rv = vload<T, VEC>(r + i), zv;
-      const vec_t<T, VEC> qv = vload<T, VEC>(q + i);
-      vec_t<T, VEC> gv;
-      if (cls) {
-        const unsigned char c = cls[i / VEC];
-        const T g0 = c == kClsRegular ? (T)6 : (T)0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) gv[j] = g0;
-        if (c == kClsMixed) gv = vload<T, VEC>(diag + i);
-      } else {
-        gv = vload<T, VEC>(diag + i);
-      }
-      if (XUPD) {
-        vec_t<T, VEC> xv = vload<T, VEC>(x + i);
-        const vec_t<T, VEC> dv = vload<T, VEC>(d + i);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) xv[j] = (T)((double)xv[j] + alpha * (double)dv[j]);
-        vstore<T, VEC>(x + i, xv);
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        rv[j] = (T)((double)rv[j] - alpha * (double)qv[j]);
-        const double zz = jac_z((double)rv[j], (double)gv[j]);
-        zv[j] = (T)zz;
-        arr += (double)rv[j] * (double)rv[j];
-        arz += (double)rv[j] * zz;
-      }
-      vstore<T, VEC>(r + i, rv);
-      vstore<T, VEC>(z + i, zv);
-    } else {
-      if (XUPD) x[i] = (T)((double)x[i] + alpha * (double)d[i]);
-      const T rn = (T)((double)r[i] - alpha * (double)q[i]);
-      const double zz = jac_z((double)rn, (double)diag[i]);
-      r[i] = rn;
-      z[i] = (T)zz;
-      arr += (double)rn * (double)rn;
-      arz += (double)rn * zz;
-    }
-  });
-  const double t1 = block_sum<kBlock>(arr);
-  const double t2 = block_sum<kBlock>(arz);
-  double rr, rz;
-  if (!last_block_total2(part_rr, part_rz, blockIdx.x, t1, t2, gridDim.x, ticket, gridDim.x, &rr, &rz)) return;
-  if (sl.on) {      // slab loop: both dot products over all ranks (two episodes of the window all-reduce), then the bookkeeping
-    if (threadIdx.x >= kWave) return;
-    bool ok;
-    rr = slab_allreduce_wave(sl.pd, sl.ring[0], sl.tag[0], rr, &ok);
-    if (!ok) { if (threadIdx.x == 0) slab_fail(scal, 1); return; }
-    rr = __shfl(rr, 0, kWave);
-    rz = slab_allreduce_wave(sl.pd, sl.ring[1], sl.tag[1], rz, &ok);
-    if (!ok) { if (threadIdx.x == 0) slab_fail(scal, 1); return; }
-  }
-  if (threadIdx.x == 0) jac_book(scal, hist, hist_cap, par, dq, rr, rz);
-}
+// (k_jac_update_rz, jac_book, JacSlab: mfs_cg_core.h -- the viscosity engine's Jacobi loop uses them too)
 
 }  // namespace mfs
 

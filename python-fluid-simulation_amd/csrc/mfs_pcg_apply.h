@@ -148,7 +148,7 @@ k_pcg_apply_direct(const T* __restrict__ v, T* __restrict__ out, const T* __rest
 // fluid solve almost every vector is ZERO or REGULAR, so the kernel's HBM traffic
 // drops from 6 to ~2.5 scalars per cell.  Lanes of non-MIXED vectors issue no
 // coefficient request at all (exec-masked loads over class constants).
-enum : unsigned char { kClsZero = 0, kClsRegular = 1, kClsMixed = 2 };
+// (kClsZero / kClsRegular / kClsMixed: mfs_cg_core.h -- the Jacobi r / z update reads the class bytes too)
 
 template <typename T, int VEC>
 struct CoefVec {

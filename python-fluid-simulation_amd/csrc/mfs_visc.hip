@@ -1568,6 +1568,31 @@ static int vcg_jac_iteration(mfs_vcg3d* h, hipStream_t st) {
   ++h->c.iter_enq;
   return MFS_OK;
 }
+
+// the same iteration with z STORED (aligned vectors): the r update reads diag once, writes r and z = r / diag (into the
+// fused loop's partner buffer, idle here) and its last block closes the iteration; the second phase x += alpha d,
+// d = z + beta d streams five arrays.  10 instead of 11 scalars per DOF, two reduction-free streaming kernels:
+// 256^3 fp32 660 -> see profiles/r02_jacobi_time_step.txt
+template <typename T, int VEC>
+static int vcg_jac_iteration_z(mfs_vcg3d* h, hipStream_t st) {
+  int e, np = 0;
+  if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, false, st, &np))) return e;
+  h->c.n_part_dq = np;
+  const int grid = core_vec_grid(h->c, true);
+  const int par = (int)(h->c.iter_enq & 1);
+  hipLaunchKernelGGL((k_jac_update_rz<T, VEC, false>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)h->c.d, (T*)h->c.r,
+                     (const T*)h->c.q, (const T*)h->diag, (T*)h->d2, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
+                     h->c.part_dq, h->c.n_part_dq, (const unsigned char*)nullptr, h->c.hist, kHistCap, h->c.tickets, JacSlab{});
+  const bool ntx = 5.0 * (double)h->n * h->c.elt > 200e6;
+  if (ntx) hipLaunchKernelGGL((k_jac_dx<T, VEC, true>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (T*)h->c.d, (const T*)h->d2, h->n,
+                              h->c.scal, (double)h->c.iter_enq);
+  else hipLaunchKernelGGL((k_jac_dx<T, VEC, false>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (T*)h->c.d, (const T*)h->d2, h->n,
+                          h->c.scal, (double)h->c.iter_enq);
+  MFS_LAUNCH_CHECK();
+  h->c.n_part_rr = grid;
+  ++h->c.iter_enq;
+  return MFS_OK;
+}
 }  // extern "C++"
 
 int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
@@ -1576,10 +1601,15 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   if (h->jacobi) {
     MFS_REQUIRE(h->diag_ready, "Jacobi loop: mfs_vcg3d_begin has not built the diagonal");
     const bool vec = core_vec_ok(h->c);
+    // z stored (two streaming kernels, a reduction tail) pays beyond the caches; launch-bound sizes keep the form whose
+    // consumers fold the partial sums themselves (MFS_VISC_JACOBI_Z = 0 / 1 overrides)
+    const int zk = env_int("MFS_VISC_JACOBI_Z", -1);
+    const bool zform = zk < 0 ? (5.0 * (double)h->n * h->c.elt > 100e6) : (zk != 0);
     for (int64_t i = 0; i < n; ++i) {
       int e;
-      if (h->dt == MFS_F32) e = vec ? vcg_jac_iteration<float, 4>(h, st) : vcg_jac_iteration<float, 1>(h, st);
-      else e = vec ? vcg_jac_iteration<double, 2>(h, st) : vcg_jac_iteration<double, 1>(h, st);
+      if (vec && zform) e = h->dt == MFS_F32 ? vcg_jac_iteration_z<float, 4>(h, st) : vcg_jac_iteration_z<double, 2>(h, st);
+      else if (vec) e = h->dt == MFS_F32 ? vcg_jac_iteration<float, 4>(h, st) : vcg_jac_iteration<double, 2>(h, st);
+      else e = h->dt == MFS_F32 ? vcg_jac_iteration<float, 1>(h, st) : vcg_jac_iteration<double, 1>(h, st);
       if (e) return e;
     }
     return MFS_OK;
