@@ -164,6 +164,11 @@ class SlabNotebookSimulation(NotebookSimulation):
 
     def __init__(self, *args, dist, group=None, transport="auto", **kw):
         self.dist, self.group, self._transport = dist, group, transport
+        if kw.get("jacobi"):
+            import warnings
+            warnings.warn("jacobi=True is an option of the single-GPU NotebookSimulation: the slab-decomposed time step runs the "
+                          "reference's unpreconditioned CG loops", RuntimeWarning, stacklevel=2)
+            kw["jacobi"] = False
         super().__init__(*args, **kw)
 
     def _make_solvers(self):
