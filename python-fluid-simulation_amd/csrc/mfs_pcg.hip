@@ -713,28 +713,28 @@ static int pcg_iterate_lean(mfs_pcg3d* h, int64_t n, hipStream_t st) {
 // the resident loop (mfs_pcg_resident.h): a grid that fits W workgroups' registers, the fused loop's preconditions
 // (aligned vectors, compressed coefficient classes), no deferred x update pending
 static bool resident_ok(const mfs_pcg3d* h) {
-  return h->resident != 0 && h->res.ok && h->res_ar && native_fuse_ok(h) && !h->slab_loop && h->defer_x <= 0 &&
-         !h->x_owed && ((uintptr_t)h->c.x % 16 == 0);
+  return h->resident != 0 && h->res.ok && h->res_ar && (native_fuse_ok(h) || (jac_fuse_ok(h) && core_vec_ok(h->c))) &&
+         !h->slab_loop && h->defer_x <= 0 && !h->x_owed && ((uintptr_t)h->c.x % 16 == 0);
 }
 
 extern "C++" {
 template <typename T, int VEC>
 static int pcg_launch_resident(mfs_pcg3d* h, const ResArgs& a, hipStream_t st) {
   const ResPlan& p = h->res;
+#define MFS_RES_ONE(KVV, ASY, JCB)                                                                                \
+  do {                                                                                                            \
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_pcg_resident<T, VEC, KVV, ASY, JCB>,                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                     \
+    hipLaunchKernelGGL((k_pcg_resident<T, VEC, KVV, ASY, JCB>), dim3(p.W), dim3(kResBlock), p.lds, st, a);        \
+  } while (0)
 #define MFS_RES(KVV)                                                                                              \
   do {                                                                                                            \
-    if (h->asym) {                                                                                                \
-      MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_pcg_resident<T, VEC, KVV, true>,                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                   \
-      hipLaunchKernelGGL((k_pcg_resident<T, VEC, KVV, true>), dim3(p.W), dim3(kResBlock), p.lds, st, a);          \
-    } else {                                                                                                      \
-      MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_pcg_resident<T, VEC, KVV, false>,                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                   \
-      hipLaunchKernelGGL((k_pcg_resident<T, VEC, KVV, false>), dim3(p.W), dim3(kResBlock), p.lds, st, a);         \
-    }                                                                                                             \
+    if (h->jacobi) { if (h->asym) MFS_RES_ONE(KVV, true, true); else MFS_RES_ONE(KVV, false, true); }             \
+    else           { if (h->asym) MFS_RES_ONE(KVV, true, false); else MFS_RES_ONE(KVV, false, false); }           \
   } while (0)
   if (p.kv <= 1) MFS_RES(1); else if (p.kv == 2) MFS_RES(2); else if (p.kv == 3) MFS_RES(3); else MFS_RES(4);
 #undef MFS_RES
+#undef MFS_RES_ONE
   MFS_LAUNCH_CHECK();
   return MFS_OK;
 }
@@ -743,12 +743,13 @@ static int pcg_launch_resident(mfs_pcg3d* h, const ResArgs& a, hipStream_t st) {
 static int pcg_iterate_resident(mfs_pcg3d* h, int64_t n, hipStream_t st) {
   while (n > 0) {
     const int nb = (int)std::min<int64_t>(n, 1 << 20);
-    if (h->res_epoch > 0xf0000000u - 2u * (unsigned)nb) {          // tags about to wrap: start over on clean tables
+    const unsigned per_it = h->jacobi ? 3u : 2u;                   // episode tags per iteration (Jacobi: d.q, r.r, r.z)
+    if (h->res_epoch > 0xf0000000u - per_it * (unsigned)nb) {      // tags about to wrap: start over on clean tables
       MFS_HIP_TRY(hipMemsetAsync(h->res_ar, 0, res_ws_bytes(h->n, h->c.elt), st));
       h->res_epoch = 0;
     }
     ResArgs a{};
-    a.x = h->c.x; a.r = h->c.r; a.q = h->c.q; a.dbuf[0] = h->c.d; a.dbuf[1] = h->d2;
+    a.x = h->c.x; a.r = h->c.r; a.q = h->c.q; a.dbuf[0] = h->c.d; a.dbuf[1] = h->d2; a.zb = h->zb;
     a.diag = h->diag; a.cx = h->cx; a.cy = h->cy; a.cz = h->cz; a.cz2 = h->cz2; a.cls = h->cls;
     a.Nx = h->Nx; a.Ny = h->Ny; a.Nz = h->Nz; a.Px = h->res.Px; a.Py = h->res.Py; a.bxm = h->res.bxm; a.bym = h->res.bym;
     a.scal = h->c.scal; a.hist = h->c.hist; a.hist_cap = kHistCap;
@@ -761,7 +762,7 @@ static int pcg_iterate_resident(mfs_pcg3d* h, int64_t n, hipStream_t st) {
     a.test_drop_wg = env_int("MFS_RES_TEST_DROP_WG", -1);
     int e = h->dt == MFS_F32 ? pcg_launch_resident<float, 4>(h, a, st) : pcg_launch_resident<double, 2>(h, a, st);
     if (e) return e;
-    h->res_epoch += 2u * (unsigned)nb;
+    h->res_epoch += per_it * (unsigned)nb;
     h->c.iter_enq += nb;
     n -= nb;
   }
@@ -772,7 +773,7 @@ int mfs_pcg3d_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   if (h->jacobi || resident_ok(h) || !lean_ok(h))
     if (int e = pcg_close_pending(h, (hipStream_t)stream)) return e;
-  if (!h->jacobi && resident_ok(h)) return pcg_iterate_resident(h, n, (hipStream_t)stream);
+  if (resident_ok(h)) return pcg_iterate_resident(h, n, (hipStream_t)stream);      // (plain or Jacobi: template flag JAC)
   if (!h->jacobi && lean_ok(h)) return pcg_iterate_lean(h, n, (hipStream_t)stream);
   if (h->jacobi && jac_fuse_ok(h) && core_vec_ok(h->c)) {
     for (int64_t i = 0; i < n; ++i) {
@@ -859,7 +860,7 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
 int mfs_pcg3d_loop_info(mfs_pcg3d* h) {
   if (!h) return 0;
   if (!h->c.x) return h->jacobi ? 4 : 0;          // not bound yet: only the mode is known
-  const bool res = !h->jacobi && resident_ok(h);
+  const bool res = resident_ok(h);
   const bool jf = jac_fuse_ok(h) && core_vec_ok(h->c);
   return ((native_fuse_ok(h) || jf) ? 1 : 0) | (!res && xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0) | (res ? 8 : 0);
 }
@@ -885,7 +886,7 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   while (!done && enq < max_iter) {
     // the resident loop stops by itself inside a batch (one launch), so a longer batch costs nothing but saves the
     // launch, the reload of the state and the poll: at least 128 iterations per look there
-    const int64_t every = (!h->jacobi && resident_ok(h)) ? std::max<int64_t>(check_every, 128) : check_every;
+    const int64_t every = resident_ok(h) ? std::max<int64_t>(check_every, 128) : check_every;
     const int64_t n = std::min(every, max_iter - enq);
     if (int e = mfs_pcg3d_iterate(h, n, stream)) return e;
     if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;

@@ -60,6 +60,7 @@ constexpr int kResRecStrideMax = 1024;             // u64 words between two work
 
 struct ResArgs {
   void *x, *r, *q, *dbuf[2];
+  void* zb;                                         // JAC: z = r / diag written back beside r
   const void *diag, *cx, *cy, *cz, *cz2;
   const unsigned char* cls;
   int Nx, Ny, Nz, Px, Py, bxm, bym;
@@ -144,6 +145,64 @@ __device__ __forceinline__ double res_allreduce_end(u64* ar, int rec_stride, int
   return s_tot;
 }
 
+// the same exchange for TWO values at once (Jacobi: r.r and r.z): two records, episodes tag1 / tag2, one barrier each way
+__device__ __forceinline__ void res_allreduce_begin2(double v1, double v2, u64* ar, int rec_stride, unsigned tag1, unsigned tag2) {
+  __shared__ double s_w2[2][kResBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  v1 = wave_sum(v1);
+  v2 = wave_sum(v2);
+  if (lane == 0) { s_w2[0][wave] = v1; s_w2[1][wave] = v2; }
+  MFS_LDS_BARRIER();
+  if (wave == 0 && lane < 2) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kResBlock / kWave; ++w) t += s_w2[lane][w];
+    const unsigned tag = lane == 0 ? tag1 : tag2;
+    u64* tab = ar + ((size_t)(tag % kResRing) * kResMaxW + blockIdx.x) * rec_stride;
+    const u64 bits = (u64)__double_as_longlong(t);
+    dev_store(tab + 0, ((u64)tag << 32) | (bits & 0xffffffffull));
+    dev_store(tab + 1, ((u64)tag << 32) | (bits >> 32));
+  }
+}
+
+__device__ __forceinline__ void res_allreduce_end2(u64* ar, int rec_stride, int W, unsigned tag1, unsigned tag2, u64 timeout_ticks,
+                                                   bool* ok, double* t1, double* t2) {
+  __shared__ double s_tot2[2];
+  __shared__ int s_ok2;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (wave == 0) {
+    double c[2] = {0.0, 0.0};
+    bool good = true;
+    if (lane < W) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const unsigned tag = m == 0 ? tag1 : tag2;
+        const u64* g = ar + ((size_t)(tag % kResRing) * kResMaxW + lane) * rec_stride;
+        res_u64x2 w = dev_load2(g);
+        bool got = (w[0] >> 32) == tag && (w[1] >> 32) == tag;
+        for (int spin = 0; spin < 64 && !got; ++spin) { w = dev_load2(g); got = (w[0] >> 32) == tag && (w[1] >> 32) == tag; }
+        if (!got && good) {
+          const u64 t0 = wall_clock64();
+          for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+            w = dev_load2(g);
+            if ((w[0] >> 32) == tag && (w[1] >> 32) == tag) break;
+            if (wall_clock64() - t0 > timeout_ticks) { good = false; break; }
+          }
+        }
+        c[m] = __longlong_as_double((long long)((w[1] << 32) | (w[0] & 0xffffffffull)));
+      }
+    }
+    good = __all(good);
+    const double a1 = wave_sum(c[0]), a2 = wave_sum(c[1]);
+    if (lane == 0) { s_tot2[0] = a1; s_tot2[1] = a2; s_ok2 = good ? 1 : 0; }
+  }
+  MFS_LDS_BARRIER();
+  *ok = s_ok2 != 0;
+  *t1 = s_tot2[0];
+  *t2 = s_tot2[1];
+}
+
 // r of one z-vector as tagged granules (agent scope), and back
 __device__ __forceinline__ void dev_store2(u64* p, u64 a, u64 b) {
   // 16-byte write-through store of TWO granules (a store torn between its halves is harmless: each validates itself).
@@ -205,7 +264,10 @@ struct ResBox {
   int pitch_y;                   // LDS image: element offset of (lx, ly, z) = ((lx + 1) * pitch_y + (ly + 1)) * Nz + z
 };
 
-template <typename T, int VEC, int KV, bool ASYM>
+// JAC: the opt-in Jacobi-preconditioned iteration (z = r / diag, delta = r.z; stopping rule r.r < tol^2 unchanged): z of the
+// box faces travels instead of r, r.r and r.z share one exchange (two records), THREE episode tags per iteration, and z is
+// written back beside r (the launch-per-phase Jacobi loop's operand, mfs_pcg.hip).
+template <typename T, int VEC, int KV, bool ASYM, bool JAC = false>
 __global__ void __launch_bounds__(kResBlock, 2)
 k_pcg_resident(ResArgs a) {
   double* const scal = a.scal;
@@ -273,7 +335,8 @@ k_pcg_resident(ResArgs a) {
       if (j0 == 0) dv[k] = dp;
       else {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) dv[k][j] = (T)((double)rv[k][j] + beta0 * (double)dp[j]);
+        for (int j = 0; j < VEC; ++j)
+          dv[k][j] = (T)((JAC ? (double)(T)jac_z((double)rv[k][j], (double)c_dg[k][j]) : (double)rv[k][j]) + beta0 * (double)dp[j]);
       }
       vstore<T, VEC>(img + lofs[k], dv[k]);
     }
@@ -297,7 +360,12 @@ k_pcg_resident(ResArgs a) {
     const vec_t<T, VEC> dp = vload<T, VEC>(dsrc + g);
     vec_t<T, VEC> o = dp;
     if (j0 != 0 && own) {
-      const vec_t<T, VEC> rh = vload<T, VEC>(r + g);
+      vec_t<T, VEC> rh = vload<T, VEC>(r + g);
+      if (JAC) {
+        const vec_t<T, VEC> gh = vload<T, VEC>(dg + g);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rh[j] = (T)jac_z((double)rh[j], (double)gh[j]);
+      }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] = (T)((double)rh[j] + beta0 * (double)dp[j]);
     }
@@ -321,7 +389,7 @@ k_pcg_resident(ResArgs a) {
     RES_STAMP(9);
     const int64_t jj = j0 + it;
     const int par = (int)(jj & 1);
-    const unsigned tag = a.tag0 + 2u * (unsigned)it;
+    const unsigned tag = a.tag0 + (JAC ? 3u : 2u) * (unsigned)it;
     jl = jj; ran = true;
     // ---- q = A d, d.q
     double acc = 0.0;
@@ -365,24 +433,33 @@ k_pcg_resident(ResArgs a) {
     const double alpha = delta / dq;
     u64* const mir = a.mirror + (size_t)par * (size_t)a.Nx * sx * Gran<T>::N;
     acc = 0.0;
+    double acz = 0.0;
+    vec_t<T, VEC> zv_[JAC ? KV : 1];                       // JAC: z = r / diag, rounded to the state type like the stored z
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
+      if (JAC) zv_[JAC ? k : 0] = vec_t<T, VEC>{};
       if (!(flags[k] & 1u)) continue;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         rv[k][j] = (T)((double)rv[k][j] - alpha * (double)qv[k][j]);
         acc += (double)rv[k][j] * (double)rv[k][j];
+        if (JAC) {
+          const double zz = jac_z((double)rv[k][j], (double)c_dg[k][j]);
+          zv_[JAC ? k : 0][j] = (T)zz;
+          acz += (double)rv[k][j] * zz;
+        }
       }
     }
     RES_STAMP(3);
-    res_allreduce_begin(acc, a.ar, a.rec_stride, tag + 1u);
+    if (JAC) res_allreduce_begin2(acc, acz, a.ar, a.rec_stride, tag + 1u, tag + 2u);
+    else res_allreduce_begin(acc, a.ar, a.rec_stride, tag + 1u);
     RES_STAMP(4);
     // faces after the record HAS BEEN ISSUED (second barrier: the other waves do not overtake wave 0): their
     // write-through stores take a microsecond to drain, and a record queued behind them is a microsecond late everywhere
     MFS_LDS_BARRIER();
 #pragma unroll
     for (int k = 0; k < KV; ++k)
-      if ((flags[k] & 9u) == 9u) res_publish<T, VEC>(mir, gofs[k], rv[k], tag + 1u);
+      if ((flags[k] & 9u) == 9u) res_publish<T, VEC>(mir, gofs[k], JAC ? zv_[JAC ? k : 0] : rv[k], tag + 1u);
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
 #pragma unroll
@@ -400,31 +477,35 @@ k_pcg_resident(ResArgs a) {
     }
     if (!hok) s_fail = 1;
     RES_STAMP(5);
-    const double rr = res_allreduce_end(a.ar, a.rec_stride, W, tag + 1u, a.timeout_ticks, &ok);      // (its barrier publishes s_fail too)
+    double rr, rz = 0.0;
+    if (JAC) res_allreduce_end2(a.ar, a.rec_stride, W, tag + 1u, tag + 2u, a.timeout_ticks, &ok, &rr, &rz);
+    else rr = res_allreduce_end(a.ar, a.rec_stride, W, tag + 1u, a.timeout_ticks, &ok);      // (its barrier publishes s_fail too)
     if (!ok) { if (tid == 0) slab_fail(scal, kErrArTimeout); ran = false; break; }
+    const double dnew = JAC ? rz : rr;                      // delta of the next iteration
     if (s_fail) { if (tid == 0) slab_fail(scal, kErrHaloTimeout); ran = false; break; }
     if (blockIdx.x == 0 && tid == 0) {
       // cg_book (mfs_cg_core.h) with its operands already in registers: stores only, nothing on this thread's path waits
       const int64_t itc = it0 + it;
       if (2 * itc + 2 < a.hist_cap) { a.hist[2 * itc + 1] = dq; a.hist[2 * itc + 2] = rr; }
       scal[S_ITERS] = (double)(itc + 1);
-      scal[S_RING + (par ^ 1)] = rr;
+      scal[S_RING + (par ^ 1)] = dnew;
       scal[S_RR] = rr; scal[S_DQ] = dq; scal[S_DELTA] = delta; scal[S_LASTRR] = rr;
+      if (JAC) scal[S_RZ] = rz;
       scal[S_ALPHA] = delta / dq;
       if (const int bad = cg_health(dq, rr)) { scal[S_ERR] = (double)bad; scal[S_DONE] = 1.0; }
       else if (rr < tol2) scal[S_DONE] = 1.0;
-      else scal[S_BETA] = rr / delta;
+      else scal[S_BETA] = dnew / delta;
     }
     RES_STAMP(6);
     if (cg_health(dq, rr) != 0 || rr < tol2 || it + 1 == a.n_iter) break;      // d_{j+1} is owed, as after every batch
     // ---- d = r + beta d: own vectors from registers, the halo from the neighbours' published r
-    const double beta = rr / delta;
-    delta = rr;
+    const double beta = dnew / delta;
+    delta = dnew;
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
       if (!(flags[k] & 1u)) continue;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) dv[k][j] = (T)((double)rv[k][j] + beta * (double)dv[k][j]);
+      for (int j = 0; j < VEC; ++j) dv[k][j] = (T)((JAC ? (double)zv_[JAC ? k : 0][j] : (double)rv[k][j]) + beta * (double)dv[k][j]);
       vstore<T, VEC>(img + lofs[k], dv[k]);
     }
     for (int h = tid; h < nh; h += kResBlock) {
@@ -457,6 +538,12 @@ k_pcg_resident(ResArgs a) {
     vstore<T, VEC>(x + gofs[k], xv[k]);
     vstore<T, VEC>(r + gofs[k], rv[k]);
     vstore<T, VEC>(dout + gofs[k], dv[k]);
+    if (JAC) {      // z of the final r: the operand the launch-per-phase Jacobi loop (and pcg_home_d) takes from the engine's z buffer
+      vec_t<T, VEC> zo;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) zo[j] = (T)jac_z((double)rv[k][j], (double)c_dg[k][j]);
+      vstore<T, VEC>((T*)a.zb + gofs[k], zo);
+    }
     const bool first = flags[k] & 2u, last = flags[k] & 4u;
     if (!first && !last) vstore<T, VEC>(q + gofs[k], qv[k]);
     else {

@@ -22,13 +22,13 @@ def T(a):
     return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
 
 
-def _run(gres, prec, resident, iters=12, check_every=5, seed=None, switch=False):
+def _run(gres, prec, resident, iters=12, check_every=5, seed=None, switch=False, jacobi=False):
     import solver.CGSolverBuffer as B
     import solver.PressureCGSolver3D as P
     seed = sum(gres) if seed is None else seed
     sc = scenes.pressure_scene_3d(gres, seed=seed, vel_dtype=np.float32, solid_velocity=bool(seed & 1))
     buf = B.CGSolverBuffer(gres, precision=prec, device=DEV)
-    s = P.PressureCGSolver3D(buf, gres, sc["bound_size"], check_every=check_every)
+    s = P.PressureCGSolver3D(buf, gres, sc["bound_size"], check_every=check_every, jacobi=jacobi)
     s.max_iter = iters
     e = s._engine
     e.set_resident(resident)
@@ -74,6 +74,59 @@ def test_resident_loop_against_the_oracle_history():
     ref.solve(*rv, sc["sphi"], sc["sv"], sc["lphi"], tol=1e-30, max_iter=12, raise_on_fail=False)
     n = min(len(a["hist"]), len(ref.history), 21)
     np.testing.assert_allclose(a["hist"][:n], np.array(ref.history)[:n], rtol=1e-9)
+
+
+@pytest.mark.parametrize("gres", [(48, 80, 48), (24, 20, 32), (12, 16, 8), (33, 17, 64)], ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_resident_jacobi_loop_matches_launch_per_phase_jacobi_loop(gres, prec):
+    """the opt-in Jacobi iteration inside the resident launch (z = r / diag from registers, z faces exchanged, r.r and r.z in
+    one exchange) against the fused two-launch Jacobi loop"""
+    iters = 12 if int(np.prod(gres)) >= 2000 else 6
+    a = _run(gres, prec, True, iters, jacobi=True)
+    b = _run(gres, prec, False, iters, jacobi=True)
+    assert a["info"]["jacobi"] and b["info"]["jacobi"] and not b["info"]["resident"]
+    assert a["info"]["resident"], "the grid was expected to qualify for the resident loop"
+    assert a["iters"] == b["iters"]
+    rt = 1e-9 if prec == "fp64" else 5e-5
+    np.testing.assert_allclose(a["hist"], b["hist"], rtol=rt, atol=1e-16 * max(b["hist"][0], 1e-300))
+    for k in ("x", "d", "r", "q"):
+        ref = b[k]
+        scale = float(ref.abs().max()) or 1.0
+        assert float((a[k] - ref).abs().max()) <= (1e-8 if prec == "fp64" else 2e-4) * scale, k
+
+
+def test_jacobi_batches_of_both_loops_follow_each_other():
+    """Jacobi: resident batch -> fused two-launch batch -> resident ... (z handed over through the engine's buffer)"""
+    import solver.CGSolverBuffer as B
+    import solver.PressureCGSolver3D as P
+    import solver.SolidFraction3D as S
+    gres = (24, 20, 32)
+    sc = scenes.pressure_scene_3d(gres, seed=3, vel_dtype=np.float32)
+    out = []
+    for plan in ((True, False, True, False), (False, False, False, False), (False, True, True, False)):
+        buf = B.CGSolverBuffer(gres, precision="fp64", device=DEV)
+        s = P.PressureCGSolver3D(buf, gres, sc["bound_size"], jacobi=True)
+        e = s._engine
+        sphi, lphi = T(sc["sphi"]), T(sc["lphi"])
+        S.compute_solid_frac(gres, sphi, s.wx, s.wy, s.wz)
+        P.initialize_solver(s.cell_size, s._g, T(sc["vx"]), T(sc["vy"]), T(sc["vz"]), sphi, T(sc["sv"]), lphi, buf.b,
+                            s.wx, s.wy, s.wz)
+        e.setup(lphi, s.wx, s.wy, s.wz)
+        e.bind(buf.b, s.x, buf.d, buf.r, buf.q)
+        e.begin(0.0)
+        for res in plan:
+            e.set_resident(res)
+            e.iterate(3)
+        e.finish()
+        st = e.poll()
+        out.append((st["iterations"], np.array(e.history()), s.x.clone(), buf.d.clone(), buf.r.clone()))
+    for o in out:
+        assert o[0] == 12
+    for o in (out[0], out[2]):
+        np.testing.assert_allclose(o[1], out[1][1], rtol=1e-9)
+        for i in (2, 3, 4):
+            scale = float(out[1][i].abs().max()) or 1.0
+            assert float((o[i] - out[1][i]).abs().max()) <= 1e-8 * scale, i
 
 
 def test_batches_of_both_loops_follow_each_other():
