@@ -14,7 +14,7 @@ P4="WRITE_SIZE"
 i=0
 for C in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_p$i -- python3 $R/tools/bench_viscosity.py $N f32 20 > $R/gpurun_out/${TAG}_p$i.log 2>&1 || true
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_p$i -- python3 $R/tools/bench_viscosity.py $N ${PMC_DT:-f32} 20 > $R/gpurun_out/${TAG}_p$i.log 2>&1 || true
 done
 python3 - $R/gpurun_out/${TAG} <<'PY'
 import csv, glob, sys, collections
