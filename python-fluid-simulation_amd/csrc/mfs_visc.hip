@@ -851,7 +851,7 @@ static int vcg_march_block(const mfs_vcg3d* h) {
   if (knob == 256) return 256;
   const bool fits512 = vm_lds_bytes<T, VEC, 512>(Nz) <= 152 * 1024 && 2 * (Nz / VEC) <= 512;
   if (knob == 512 && fits512) return 512;
-  if (sizeof(T) == 8 && vm_lds_bytes<T, VEC, 256>(Nz) > 80 * 1024 && fits512) return 512;
+  if (vm_lds_bytes<T, VEC, 256>(Nz) > 80 * 1024 && fits512) return 512;      // fp64 from Nz ~ 150, fp32 from Nz ~ 300
   return 256;
 }
 

@@ -94,7 +94,7 @@ def test_march_is_what_runs_by_default():
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("gres", [(12, 12, 12), (20, 24, 36), (9, 70, 16), (7, 5, 128), (10, 14, 256), (48, 80, 48)],
+@pytest.mark.parametrize("gres", [(12, 12, 12), (20, 24, 36), (9, 70, 16), (7, 5, 128), (10, 14, 256), (48, 80, 48), (6, 10, 512)],
                          ids=lambda g: "x".join(map(str, g)))
 def test_march_with_512_thread_workgroups(gres, dt, monkeypatch):
     """tiles of 512 z-vectors (one workgroup of eight waves per CU: what fp64 state takes on rows too long for two 256-vector

@@ -6,8 +6,10 @@ sys.path[:0] = [os.path.join(REPO, "python-fluid-simulation_amd"), REPO]
 import torch
 from mfs import scenes
 import solver.ViscosityCGSolver3D as V
-N = int(sys.argv[1]); dts = sys.argv[2] if len(sys.argv) > 2 else "f32"; tag = sys.argv[3] if len(sys.argv) > 3 else ""
-dev = torch.device("cuda:0"); gres = (N, N, N)
+dts = sys.argv[2] if len(sys.argv) > 2 else "f32"; tag = sys.argv[3] if len(sys.argv) > 3 else ""
+gres = tuple(int(v) for v in sys.argv[1].split("x")) if "x" in sys.argv[1] else (int(sys.argv[1]),) * 3      # N or NxxNyxNz
+N = sys.argv[1]
+dev = torch.device("cuda:0")
 sc = scenes.viscosity_scene_3d(gres, seed=3, device=dev)
 s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision=dts, device=dev)
 scale = sc["dt"] / s.cell_vol / sc["rho"]
@@ -31,7 +33,7 @@ its = []
 for _ in range(3):
     t0 = time.perf_counter(); e.iterate(40); torch.cuda.synchronize(); its.append(round((time.perf_counter() - t0) / 40 * 1e6, 1))
 res["iter_us"] = its
-cells = N ** 3
+cells = gres[0] * gres[1] * gres[2]
 esz = 4 if dts == "f32" else 8
 res["apply_alg_GBs(13 scalars + 3 mask bytes per cell)"] = round((13 * esz + 3) * cells / (res["apply_b2b_us"] * 1e-6) / 1e9, 1)
 print(json.dumps(res))
