@@ -764,11 +764,19 @@ def main():
         # ---- BASELINE config 3 (viscosity CG 128^3, with its own oracle check) and the same solver beyond the Infinity
         # Cache; the opt-in Jacobi loop on the bench workload
         if world == 1 and transport == "single" and args.dtype == "f32" and not args.no_f64_line and not args.local_grid:
-            cfg2_line = config2_leg(args, torch, dev, seed)
-            visc_line = {"config3_128": viscosity_leg(torch, dev, 128, 200, True),
-                         "n256": viscosity_leg(torch, dev, 256, 60, False)}
-            jac_line = jacobi_leg(args, torch, dev, tdt, lgres, seed)
-            jac_line["viscosity"] = viscosity_jacobi_leg(torch, dev, 128)
+            def soft(fn, *a):
+                """a side leg must not take the headline down with it: its failure is reported in its place (and on stderr)"""
+                try:
+                    return fn(*a)
+                except Exception as exc:      # noqa: BLE001
+                    print(f"bench side leg {fn.__name__} failed: {exc!r}", file=sys.stderr, flush=True)
+                    torch.cuda.empty_cache()
+                    return {"error": repr(exc)[:400]}
+            cfg2_line = soft(config2_leg, args, torch, dev, seed)
+            visc_line = {"config3_128": soft(viscosity_leg, torch, dev, 128, 200, True),
+                         "n256": soft(viscosity_leg, torch, dev, 256, 60, False)}
+            jac_line = soft(jacobi_leg, args, torch, dev, tdt, lgres, seed)
+            jac_line["viscosity"] = soft(viscosity_jacobi_leg, torch, dev, 128)
     if world > 1:
         dist.barrier()
 
