@@ -76,3 +76,69 @@ def test_viscosity_operator_symmetric_positive(gres, seed):
     dot = lambda p, q: sum((a * b).sum() for a, b in zip(p, q))  # noqa: E731
     assert abs(dot(au, v) - dot(u, av)) < 1e-9 * (abs(dot(au, v)) + 1)
     assert dot(au, u) > 0
+
+
+def _golden_visc(name):
+    import os
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    gres = tuple(int(v) for v in g["gres"])
+    cell_vol = float(np.prod(np.array(g["bound_size"], dtype=np.float64) / np.array(gres, dtype=np.float64)))
+    scale = float(g["dt"]) / cell_vol / float(g["rho"])
+    vol = np.asarray(g["lvol"], np.float64) / (cell_vol * 0.125)
+    return g, gres, scale, float(g["mu"]), vol
+
+
+def test_visc_diag_is_the_diagonal_of_the_executed_reference_operator():
+    """visc_diag3d (operand of the opt-in Jacobi loops) against the operator restatement the goldens pin: (A e_i)_i on random faces"""
+    g, gres, scale, mu, vol = _golden_visc("v3d_a_12")
+    D = O.visc_diag3d(gres, scale, mu, g["sphi"], vol)
+    rng = np.random.default_rng(0)
+    shp = [d.shape for d in D]
+    checked = 0
+    for _ in range(60):
+        c = int(rng.integers(0, 3))
+        idx = tuple(int(rng.integers(1, s - 1)) for s in shp[c])
+        E = [np.zeros(s) for s in shp]
+        E[c][idx] = 1.0
+        Q = [np.zeros(s) for s in shp]
+        O.visc_apply3d(gres, scale, mu, *E, *Q, g["sphi"], vol)
+        assert Q[c][idx] == pytest.approx(D[c][idx], rel=1e-14, abs=0.0)
+        checked += D[c][idx] != 0.0
+    assert checked > 10
+
+
+def test_visc_cg_jacobi_solves_the_reference_system():
+    """the preconditioned restatement converges to the solution of the SAME system as the reference's loop (both iterated to 1e-12)"""
+    g, gres, scale, mu, vol = _golden_visc("v3d_a_12")
+    B = [np.array(g[k], dtype=np.float64) for k in ("bx", "by", "bz")]
+    Xj = [np.array(g[k], dtype=np.float64) for k in ("ex", "ey", "ez")]
+    itj, _ = O.visc_cg_jacobi(gres, scale, mu, B, Xj, g["sphi"], vol, 1e-12, 10000)
+    Xp = [np.array(g[k], dtype=np.float64) for k in ("ex", "ey", "ez")]
+    Q, R, Dv = ([np.zeros_like(b) for b in B] for _ in range(3))
+
+    def ap(V, Qo):
+        for q in Qo:
+            q[...] = 0.0
+        O.visc_apply3d(gres, scale, mu, *V, *Qo, g["sphi"], vol)
+    # plain CG on the three-component system (the reference's loop, :575-612), to the same tolerance
+    ap(Xp, Q)
+    R = [b - q for b, q in zip(B, Q)]
+    Dv = [r.copy() for r in R]
+    delta = sum(float(np.sum(r * r)) for r in R)
+    itp = 0
+    while delta >= 1e-24 and itp < 10000:
+        itp += 1
+        ap(Dv, Q)
+        alpha = delta / sum(float(np.sum(d * q)) for d, q in zip(Dv, Q))
+        for x, d in zip(Xp, Dv):
+            x += alpha * d
+        for r, q in zip(R, Q):
+            r -= alpha * q
+        dn = sum(float(np.sum(r * r)) for r in R)
+        Dv = [r + (dn / delta) * d for r, d in zip(R, Dv)]
+        delta = dn
+    assert itj < itp
+    nrm = max(np.abs(x).max() for x in Xp)
+    for a, b in zip(Xj, Xp):
+        assert np.abs(a - b).max() <= 1e-9 * nrm
