@@ -333,7 +333,8 @@ int mfs_vcg3d_loop_info(mfs_vcg3d* h);
  * own diagonal (vol_c + scale mu (...), :268 / :338 / :408; built once per solve), delta = r.z, convergence test unchanged
  * (r.r < tol^2).  NOT the reference's iteration (ViscosityCGSolver3D.py:575-612 is unpreconditioned): another residual
  * history, the same solution to the tolerance, far fewer iterations where partly filled cells make the diagonal span orders
- * of magnitude.  Single GPU (mfs_vcg3d_begin / iterate / solve); bit 2 of mfs_vcg3d_loop_info. */
+ * of magnitude.  Single GPU (mfs_vcg3d_begin / iterate / solve) and the window slab loop (mfs_vcg3d_slab_begin / slab_iterate:
+ * r.z all-reduced as a third episode); bit 2 of mfs_vcg3d_loop_info. */
 int mfs_vcg3d_set_jacobi(mfs_vcg3d* h, int on);
 /* 1 / 0: allow that small-problem loop (default 1; env MFS_RDX).  A launch that is not fully resident (shared GPU) times
  * out without having written anything; the next poll switches the engine to the three-launch loop for good. */

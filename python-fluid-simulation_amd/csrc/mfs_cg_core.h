@@ -717,8 +717,9 @@ k_jac_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
                 const T* __restrict__ diag, int64_t n, double* __restrict__ scal, double* __restrict__ part_rr,
                 double* __restrict__ part_rz, int par, const double* __restrict__ part_dq, int npart) {
   if (scal[S_DONE] != 0.0) return;
-  const double dq = block_total_of(part_dq, npart);
-  if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
+  // d.q: folded from the stencil launch's partials, or (npart == 0: slab loops) the all-reduced scalar
+  const double dq = npart > 0 ? block_total_of(part_dq, npart) : scal[S_DQ];
+  if (npart > 0 && blockIdx.x == 0 && threadIdx.x == 0) scal[S_DQ] = dq;
   const double alpha = scal[S_RING + par] / dq;
   double arr = 0.0, arz = 0.0;
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
@@ -753,8 +754,8 @@ k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__
                double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
                const double* __restrict__ part_rr, const double* __restrict__ part_rz, int npart) {
   if (scal[S_DONE] != 0.0) return;
-  const double rr = block_total_of(part_rr, npart);
-  const double rz = block_total_of(part_rz, npart);
+  const double rr = npart > 0 ? block_total_of(part_rr, npart) : scal[S_RR];      // (npart == 0: all-reduced scalars)
+  const double rz = npart > 0 ? block_total_of(part_rz, npart) : scal[S_RZ];
   const double delta = scal[S_RING + par];
   const bool conv = rr < scal[S_TOL2];
   const double beta = rz / delta;

@@ -1100,8 +1100,8 @@ static unsigned vslab_tag(const mfs_p2p* p, int64_t episode) {
   return 0x80000000u | ((p->epoch & 0x7ffu) << 20) | (unsigned)(episode & 0xfffff);
 }
 static int vslab_allreduce(mfs_vcg3d* h, int slot, int check_done, int64_t episode, hipStream_t st) {
-  const double* part = slot == S_DQ ? h->c.part_dq : h->c.part_rr;
-  const int count = slot == S_DQ ? h->c.n_part_dq : h->c.n_part_rr;
+  const double* part = slot == S_DQ ? h->c.part_dq : (slot == S_RZ ? h->part_rz : h->c.part_rr);
+  const int count = slot == S_DQ ? h->c.n_part_dq : h->c.n_part_rr;      // (r.z partials: one per block of the same kernel as r.r)
   hipLaunchKernelGGL(k_vslab_allreduce, dim3(1), dim3(kBlock), 0, st, part, count, h->c.scal, slot, check_done, h->p2p->dev,
                      (int)(episode & (kArRing - 1)), vslab_tag(h->p2p, episode));
   MFS_LAUNCH_CHECK();
@@ -1125,6 +1125,33 @@ static int vslab_iteration(mfs_vcg3d* h, hipStream_t st) {
   }
   if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;
   h->c.n_part_dq = np;
+  if (h->jacobi) {
+    // opt-in Jacobi iteration: three all-reduce episodes (d.q, r.r, r.z; begin used 0 and 1), the generic Jacobi kernels
+    // reading the all-reduced scalars (npart = 0); ghost planes: r = 0 there, so z = 0 and the local r.z counts owned faces
+    constexpr int VEC = VecOf<T>::N;
+    const bool vec = core_vec_ok(h->c);
+    const int gv = core_vec_grid(h->c, vec);
+    if ((e = vslab_allreduce(h, S_DQ, 1, 3 * j + 2, st))) return e;
+    if (vec)
+      hipLaunchKernelGGL((k_jac_update_xr<T, VEC>), dim3(gv), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)h->c.d, (T*)h->c.r,
+                         (const T*)h->c.q, (const T*)h->diag, h->n, h->c.scal, h->c.part_rr, h->part_rz, par, h->c.part_dq, 0);
+    else
+      hipLaunchKernelGGL((k_jac_update_xr<T, 1>), dim3(gv), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)h->c.d, (T*)h->c.r,
+                         (const T*)h->c.q, (const T*)h->diag, h->n, h->c.scal, h->c.part_rr, h->part_rz, par, h->c.part_dq, 0);
+    MFS_LAUNCH_CHECK();
+    h->c.n_part_rr = gv;
+    if ((e = vslab_allreduce(h, S_RR, 1, 3 * j + 3, st))) return e;
+    if ((e = vslab_allreduce(h, S_RZ, 1, 3 * j + 4, st))) return e;
+    if (vec)
+      hipLaunchKernelGGL((k_jac_update_d<T, VEC>), dim3(gv), dim3(kBlock), 0, st, (T*)h->c.d, (const T*)h->c.r, (const T*)h->diag,
+                         h->n, h->c.scal, h->c.hist, kHistCap, par, h->c.part_rr, h->part_rz, 0);
+    else
+      hipLaunchKernelGGL((k_jac_update_d<T, 1>), dim3(gv), dim3(kBlock), 0, st, (T*)h->c.d, (const T*)h->c.r, (const T*)h->diag,
+                         h->n, h->c.scal, h->c.hist, kHistCap, par, h->c.part_rr, h->part_rz, 0);
+    MFS_LAUNCH_CHECK();
+    ++h->c.iter_enq;
+    return MFS_OK;
+  }
   if ((e = vslab_allreduce(h, S_DQ, 1, 2 * j + 1, st))) return e;     // local partials -> d.q over all ranks
   if ((e = core_update_xr(h->c, false, st))) return e;
   if ((e = vslab_allreduce(h, S_RR, 1, 2 * j + 2, st))) return e;     // r.r over all ranks
@@ -1528,6 +1555,23 @@ int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
+  if (h->jacobi) {       // r = b - q, d = z = r / diag; r.r and r.z over all ranks (episodes 0 and 1); delta0 = r.z
+    if (int e = vcg_build_diag(h, st)) return e;
+    const int g2 = std::max(1, (int)std::min<int64_t>(h->c.grid_vec, (h->n + kBlock - 1) / kBlock));
+    if (h->dt == MFS_F32)
+      hipLaunchKernelGGL((k_jac_init<float>), dim3(g2), dim3(kBlock), 0, st, (const float*)h->c.b, (const float*)h->c.q,
+                         (const float*)h->diag, (float*)h->c.d, (float*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+    else
+      hipLaunchKernelGGL((k_jac_init<double>), dim3(g2), dim3(kBlock), 0, st, (const double*)h->c.b, (const double*)h->c.q,
+                         (const double*)h->diag, (double*)h->c.d, (double*)h->c.r, h->n, h->c.part_rr, h->part_rz);
+    MFS_LAUNCH_CHECK();
+    h->c.n_part_rr = g2;
+    if (int e = vslab_allreduce(h, S_RR, 0, 0, st)) return e;
+    if (int e = vslab_allreduce(h, S_RZ, 0, 1, st)) return e;
+    hipLaunchKernelGGL(k_jac_begin_finish, dim3(1), dim3(64), 0, st, h->c.scal, h->c.hist);
+    MFS_LAUNCH_CHECK();
+    return MFS_OK;
+  }
   if (int e = core_begin_post(h->c, st, false)) return e;        // d = r = b - q, partials of r.r
   if (int e = vslab_allreduce(h, S_RR, 0, 0, st)) return e;
   return core_begin_finish(h->c, st);

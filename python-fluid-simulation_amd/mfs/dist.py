@@ -380,12 +380,12 @@ class SlabVCG(_BoundedCollectives):
         if self.window is not None:
             ops.attach_p2p(self.window)
         self._bc_init()
-        # the opt-in Jacobi preconditioning of the viscosity loop is a single-GPU extra: the slab loops (window and
-        # collective) run the reference's unpreconditioned CG -- say so instead of silently ignoring the flag
-        if (self.multi or self.window is not None) and hasattr(ops, "loop_info") and ops.loop_info().get("jacobi"):
-            warnings.warn("SlabVCG: Jacobi preconditioning of the viscosity loop is a single-GPU extra -- the slab loop runs the "
-                          "reference's unpreconditioned CG (mfs_vcg3d_set_jacobi switched off on this engine)", RuntimeWarning,
-                          stacklevel=2)
+        # the opt-in Jacobi preconditioning runs in the single-GPU loop and in the WINDOW slab loop; the collective loop's
+        # phases are the reference's unpreconditioned CG -- say so instead of silently ignoring the flag
+        if self.multi and self.window is None and hasattr(ops, "loop_info") and ops.loop_info().get("jacobi"):
+            warnings.warn("SlabVCG: the collective slab loop has no Jacobi preconditioning (the window loop and the single-GPU "
+                          "loop do) -- running the reference's unpreconditioned CG (mfs_vcg3d_set_jacobi switched off)",
+                          RuntimeWarning, stacklevel=2)
             ops.set_jacobi(False)
 
     @property

@@ -164,12 +164,7 @@ class SlabNotebookSimulation(NotebookSimulation):
 
     def __init__(self, *args, dist, group=None, transport="auto", **kw):
         self.dist, self.group, self._transport = dist, group, transport
-        if kw.get("jacobi"):
-            import warnings
-            warnings.warn("jacobi=True is an option of the single-GPU NotebookSimulation: the slab-decomposed time step runs the "
-                          "reference's unpreconditioned CG loops", RuntimeWarning, stacklevel=2)
-            kw["jacobi"] = False
-        super().__init__(*args, **kw)
+        super().__init__(*args, **kw)      # (jacobi=True: honoured by the window slab loops; the collective loops drop it with a warning)
 
     def _make_solvers(self):
         from mfs.dist import SlabPartition
@@ -183,7 +178,10 @@ class SlabNotebookSimulation(NotebookSimulation):
         self._slab_buf = CGSolverBuffer(lg, precision=self._precision, device=dev)
         self.PressureSolver = SlabPressureCGSolver3D(self._slab_buf, g, self.GDX, dist, group, transport=self._transport)
         self.ViscositySolver = SlabViscosityCGSolver3D(g, self.BOUND_SIZE, dist, group, precision=self._precision, device=dev,
-                                                       transport=self._transport)
+                                                       transport=self._transport, jacobi=True if self._jacobi else None)
+        if self._jacobi:
+            self.PressureSolver._engine.set_jacobi(True)
+            self.DensitySolver._engine.set_jacobi(True)
 
     def _solve_grid(self, dt, tick, t):
         from mfs.dist import SlabPartition

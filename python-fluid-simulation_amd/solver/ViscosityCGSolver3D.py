@@ -180,7 +180,8 @@ class SlabViscosityCGSolver3D(ViscosityCGSolver3D):
         g = T.as_gres(gres)
         return (SlabPartition(g[0], world, rank).local_planes, g[1], g[2])
 
-    def __init__(self, gres, bound_size, dist, group=None, precision=None, device=None, check_every=32, transport="auto"):
+    def __init__(self, gres, bound_size, dist, group=None, precision=None, device=None, check_every=32, transport="auto",
+                 jacobi=None):
         from mfs.dist import SlabPartition, SlabVCG
         from mfs.p2p import P2PWindow
         gg = T.as_gres(gres)
@@ -188,7 +189,7 @@ class SlabViscosityCGSolver3D(ViscosityCGSolver3D):
         self.dist, self.group = dist, group
         self.part = SlabPartition(gg[0], dist.get_world_size(group), dist.get_rank(group))
         lg = (self.part.local_planes, gg[1], gg[2])
-        super().__init__(lg, bound_size, precision, device, check_every)
+        super().__init__(lg, bound_size, precision, device, check_every, jacobi)     # (Jacobi: window transport only, see SlabVCG)
         # cell size, cell volume and the iteration cap are the GLOBAL problem's (reference :535-537, :564)
         self.cell_size = np.array(T.as_f64_list(bound_size, 3)) / np.array(gg, dtype=np.float64)
         self.cell_vol = float(np.prod(self.cell_size))

@@ -127,7 +127,8 @@ def timestep_sharded_mode(rank, world, path, out, dtname, dev):
                                    axis=[0., 0, 1], angle=-35)
     sim = NSIM.ShardedNotebookSimulation(gres, gdx, [-0.3, 0, -0.3], rb_d, g["px0"], float(g["pdx"]), rho=float(g["rho"]),
                                          mu=float(g["mu"]), dt=float(g["dt"]), device=dev, dist=dist,
-                                         transport=os.environ.get("P2P_TEST_TRANSPORT", "auto"))
+                                         transport=os.environ.get("P2P_TEST_TRANSPORT", "auto"),
+                                         jacobi=os.environ.get("P2P_TEST_JACOBI", "0") == "1")
     sim.set_particle_velocities(g["pv0"])
     res, timings = {}, {}
     for s in range(int(g["steps"])):

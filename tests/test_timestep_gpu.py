@@ -137,6 +137,27 @@ def test_two_full_steps_particles_sharded(world, tmp_path):
         assert (res[0]["counts2"] > 0).sum() >= 2, res[0]["counts2"]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_full_steps_particles_sharded_with_the_jacobi_option(world, tmp_path):
+    """the sharded time step with all three solves Jacobi-preconditioned THROUGH THE WINDOW SLAB LOOPS (pressure, density:
+    mfs_pcg3d_slab_*; viscosity: mfs_vcg3d_slab_*): the particles against the executed-reference goldens within the default
+    path's tolerances, with fewer CG iterations than the reference's loops need on this scene"""
+    from test_p2p_gpu import _run_ranks
+    g = golden("step_a_12x16x12")
+    res = _run_ranks("step_a_12x16x12", world, tmp_path, "f64", P2P_TEST_MODE="timestep_sharded", P2P_TEST_JACOBI="1",
+                     P2P_TEST_TRANSPORT="p2p")
+    total = g["px0"].shape[0]
+    for s in range(int(g["steps"])):
+        move = np.abs(g[f"px{s + 1}"] - g["px0"]).max()
+        for r in res:
+            assert int(r[f"counts{s + 1}"].sum()) == total
+            np.testing.assert_allclose(r[f"px{s + 1}"], g[f"px{s + 1}"], rtol=0, atol=1e-4 * move * (s + 1))
+            np.testing.assert_allclose(r[f"pv{s + 1}"], g[f"pv{s + 1}"], rtol=0, atol=2e-3 * np.abs(g[f"pv{s + 1}"]).max())
+    for r in res:       # the last step's solves: 32 / 33 / 32 iterations with the reference's loops (density, viscosity, pressure)
+        assert 0 < int(r["p_iters"]) <= 16 and 0 < int(r["v_iters"]) <= 12 and 0 < int(r["d_iters"]) <= 20, \
+            (int(r["d_iters"]), int(r["v_iters"]), int(r["p_iters"]))
+
+
 def test_sharded_step_with_migration_matches_single_gpu(tmp_path):
     """a 32^3 buckling-like scene whose fluid block moves one cell per step across the slab cuts: four steps on 3 ranks
     with sharded particles against the same four steps on one GPU (no golden at this size: the single-GPU path is the

@@ -71,3 +71,37 @@ def test_slab_viscosity_matches_reference_outputs(name, world, dtname, transport
         np.testing.assert_allclose(arr, g[k], rtol=0, atol=ftol * vscale, err_msg=k)
     for arr, k in zip(a["v"], ("out_vx", "out_vy", "out_vz")):
         np.testing.assert_allclose(arr, g[k].astype(np.float64), rtol=0, atol=max(ftol, 1e-6) * vscale, err_msg=k)
+
+
+@pytest.mark.parametrize("name,world,dtname", [("v3d_a_12", 1, "f64"), ("v3d_a_12", 2, "f64"), ("v3d_c_16_mu50", 2, "f64"),
+                                               ("v3d_b_10x12x14", 3, "f64"), ("v3d_d_24", 3, "f32")])
+def test_slab_viscosity_jacobi_matches_single_domain_jacobi(name, world, dtname, tmp_path):
+    """the opt-in Jacobi iteration through the window slab loop (r.r AND r.z all-reduced through the windows, the generic
+    Jacobi kernels on the all-reduced scalars) against the single-domain Jacobi solve of the same golden scene"""
+    import torch
+    import solver.ViscosityCGSolver3D as V
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda:0")  # noqa: E731
+    s = V.ViscosityCGSolver3D(gres, g["bound_size"], precision={"f64": "fp64", "f32": "fp32"}[dtname], device="cuda:0",
+                              check_every=8, jacobi=True)
+    vx, vy, vz = T(g["in_vx"]), T(g["in_vy"]), T(g["in_vz"])
+    s.solve(float(g["dt"]), float(g["mu"]), float(g["rho"]), vx, vy, vz, T(g["sphi"]), T(g["sv"]), T(g["lphi"]), T(g["lvol"]),
+            tol=float(g["tol"]))
+    h0, it0 = s.history, s.iterations
+    assert it0 < int(g["iters"])
+    res = _run_ranks(name, world, tmp_path, dtname, P2P_TEST_MODE="viscosity", P2P_TEST_TRANSPORT="p2p", MFS_VISC_JACOBI="1")
+    assert all(str(r["transport"]) == "p2p" for r in res)
+    hists = [r["hist"] for r in res]
+    for h in hists[1:]:
+        np.testing.assert_array_equal(h, hists[0])
+    h = hists[0]
+    f64 = dtname == "f64"
+    n = min(len(h), len(h0), 17)
+    np.testing.assert_allclose(h[:n], h0[:n], rtol=1e-9 if f64 else 2e-5)
+    assert abs(int(res[0]["iters"]) - it0) <= max(1, it0 // 10)
+    a = _assemble(g, res)
+    ref = [vx, vy, vz]
+    vscale = max(float(t.double().abs().max()) for t in ref)
+    for arr, t in zip(a["v"], ref):
+        np.testing.assert_allclose(arr, t.double().cpu().numpy(), rtol=0, atol=(1e-6 if f64 else 1e-3) * vscale)

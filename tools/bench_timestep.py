@@ -44,7 +44,8 @@ if dist is None:
 else:
     # MFS_TIMESTEP_PARTICLES=replicated: the round-1 form (every rank holds all particles, whole-grid broadcasts)
     cls = NSIM.SlabNotebookSimulation if os.environ.get("MFS_TIMESTEP_PARTICLES") == "replicated" else NSIM.ShardedNotebookSimulation
-    sim = cls((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"), dist=dist)
+    sim = cls((N, N, N), gdx, bmin, rb_d, px, gdx / 2, mu=mu, device=dev, precision=os.environ.get("MFS_PRECISION"), dist=dist,
+              jacobi=os.environ.get("MFS_TIMESTEP_JACOBI", "0") == "1")     # (honoured by the window slab loops)
 sim.particle.v[:, 0] = -2.0
 torch.cuda.synchronize()
 t_setup = time.perf_counter() - t0
