@@ -277,8 +277,8 @@ __device__ __forceinline__ void vm_store(T* p, vec_t<T, VEC> o, bool first, bool
 constexpr int kVmRing = 4;
 template <int VEC, int BLOCK = kVmBlock>
 __host__ __device__ inline int vm_su(int Nz) { return 2 * Nz + BLOCK * VEC; }
-template <typename T, int VEC, int BLOCK = kVmBlock>
-__host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)kVmRing * 3 * vm_su<VEC, BLOCK>(Nz) * sizeof(T); }
+template <typename T, int VEC, int BLOCK = kVmBlock, int RING = kVmRing>
+__host__ __device__ inline size_t vm_lds_bytes(int Nz) { return (size_t)RING * 3 * vm_su<VEC, BLOCK>(Nz) * sizeof(T); }
 
 #define MFS_VM_PIN() __builtin_amdgcn_sched_barrier(0)
 // nontemporal hints (template NT; the host turns them on when the launch's working set exceeds the Infinity Cache, as the
@@ -340,7 +340,10 @@ struct VmFuse {
 // that the ring of a 256-vector tile -- two rows and two halo rows at Nz = 256 -- exceeds half the CU's LDS: there ONE
 // workgroup of 512 threads (a tile of four rows + two halo rows: the same eight waves per CU, 1.5x instead of 2x halo
 // traffic) replaces one of 256.
-template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock>
+// RING: plane slots of the LDS ring.  4: planes x-1, x, x+1 are read while x+2 is written -- ONE barrier per plane.  3 (rows so
+// long that four slots of a 512-vector tile exceed the CU's LDS: fp64 380 < Nz <= 512, fp32 760 < Nz <= 1024): plane x+2 takes the
+// slot of plane x-1, after a second barrier.
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock, int RING = kVmRing>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
                   int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
@@ -540,10 +543,10 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
 
     for (int x = x0; x < x1; ++x) {
       const int k = x - x0;
-      const T* const bm = smem + (k % kVmRing) * BUF;             // plane x-1
-      const T* const bc = smem + ((k + 1) % kVmRing) * BUF;       // plane x
-      const T* const bn = smem + ((k + 2) % kVmRing) * BUF;       // plane x+1
-      T* const bw = smem + ((k + 3) % kVmRing) * BUF;             // plane x+2 (written at the end of this step)
+      const T* const bm = smem + (k % RING) * BUF;             // plane x-1
+      const T* const bc = smem + ((k + 1) % RING) * BUF;       // plane x
+      const T* const bn = smem + ((k + 2) % RING) * BUF;       // plane x+1
+      T* const bw = smem + ((k + 3) % RING) * BUF;             // plane x+2 (written at the end of this step)
       // ---- (1) ONE barrier per plane: plane x+1's images (published at the end of the previous step) are complete,
       //      and nobody reads plane x-2's slot any more (it is written at the end of this step)
       MFS_VISC_LDS_BARRIER();
@@ -658,6 +661,8 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       }
       MFS_VM_PIN();
       // ---- (6) plane x+2 into its slot (its loads have had the whole step); next step's class samples take over
+      static_assert(!FUSE || RING == 4, "the fused form writes plane x+2's slot while the step reads the others");
+      if (RING == 3 && need_plane) MFS_VISC_LDS_BARRIER();      // plane x+2 reuses plane x-1's slot: everybody has read it
       if (need_plane) { if constexpr (FUSE) fform(2, x + 2, own_n, fl2, bw); else publish(bw, pn); }
       MFS_VM_STAMP(11);                                          // w: store + issue, publish of plane x+2 (waits for its loads)
       rg.cm = rg.cc; rg.cc = ccn;

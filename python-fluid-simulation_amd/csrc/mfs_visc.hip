@@ -842,48 +842,54 @@ static int vslab_grid(const Box3& b) {
 // each, one beyond that -- measured at 256^3 fp32: one workgroup per CU runs within 7 % of two, the kernel is paced
 // by its instruction stream, not by occupancy)
 constexpr size_t kVmMaxLds = 152 * 1024;
-// threads per workgroup of the march for this engine: 256, or 512 where fp64 rows are so long that a 256-vector tile's ring
-// leaves room for only one workgroup per CU anyway (see k_vcg_apply_march, BLOCK)
+// geometry of the march for this engine: threads per workgroup (= z-vectors per tile) * 10 + ring slots; 0: rows too long.
+// 256 x 4 wherever two such workgroups share a CU; 512 x 4 where only one 256-vector workgroup would fit anyway (fp64 from
+// Nz ~ 150, fp32 from Nz ~ 300); 512 x 3 (a second barrier per plane) where even that ring exceeds the LDS (fp64 380 < Nz <= 512)
 template <typename T, int VEC>
-static int vcg_march_block(const mfs_vcg3d* h) {
-  const int Nz = h->g.N[2];
-  const int knob = env_int("MFS_VISC_MARCH_BLOCK", 0);          // A/B: 256 / 512 forces, 0 auto
-  if (knob == 256) return 256;
-  const bool fits512 = vm_lds_bytes<T, VEC, 512>(Nz) <= 152 * 1024 && 2 * (Nz / VEC) <= 512;
-  if (knob == 512 && fits512) return 512;
-  if (vm_lds_bytes<T, VEC, 256>(Nz) > 80 * 1024 && fits512) return 512;      // fp64 from Nz ~ 150, fp32 from Nz ~ 300
-  return 256;
+static int vcg_march_geom(const mfs_vcg3d* h) {
+  const int Nz = h->g.N[2], nzv2 = 2 * (Nz / VEC);
+  const int knob = env_int("MFS_VISC_MARCH_BLOCK", 0);          // A/B: 256 / 512 / 5123 force, 0 auto
+  const bool f2564 = nzv2 <= 256 && vm_lds_bytes<T, VEC, 256, 4>(Nz) <= kVmMaxLds;
+  const bool f5124 = nzv2 <= 512 && vm_lds_bytes<T, VEC, 512, 4>(Nz) <= kVmMaxLds;
+  const bool f5123 = nzv2 <= 512 && vm_lds_bytes<T, VEC, 512, 3>(Nz) <= kVmMaxLds;
+  if (knob == 256 && f2564) return 2564;
+  if (knob == 512 && f5124) return 5124;
+  if (knob == 5123 && f5123) return 5123;
+  if (f2564 && vm_lds_bytes<T, VEC, 256, 4>(Nz) <= 80 * 1024) return 2564;
+  if (f5124) return 5124;
+  if (f2564) return 2564;
+  if (f5123) return 5123;
+  return 0;
 }
 
 template <typename T, int VEC = VecOf<T>::N>
 static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   if (!h->march || Nx < 3 || Ny < 3 || Nz % VEC != 0 || Nz < 2 * VEC) return false;
-  if (2 * (Nz / VEC) > kVmBlock) return false;
-  if (vm_lds_bytes<T, VEC>(Nz) > kVmMaxLds) return false;
+  if (vcg_march_geom<T, VEC>(h) == 0) return false;
   if (((uintptr_t)v % 16) != 0 || ((uintptr_t)out % 16) != 0) return false;
   if ((int64_t)(Ny + 1) * (Nz + 4) > (int64_t)0x7fffffff / 2) return false;     // 32-bit in-plane offsets
   return true;
 }
 
-template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock>
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock, int RING = kVmRing>
 static int vcg_march_launch_blk(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
                                 int* nparts, const VmFuse<T>* fz) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   const int ipp = (Ny - 2) * (Nz / VEC), tiles = (ipp + BLOCK - 1) / BLOCK;
   const int64_t total = (int64_t)tiles * (Nx - 2);
-  const size_t lds = vm_lds_bytes<T, VEC, BLOCK>(Nz);
+  const size_t lds = vm_lds_bytes<T, VEC, BLOCK, RING>(Nz);
   const int bpc = lds > 80 * 1024 ? 1 : h->march_bpc;
   const int gmain = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * bpc));
   const Box3 b0 = vslab_box(h, 0), b1 = vslab_box(h, 1), b2 = vslab_box(h, 2);
   const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
   static bool attr_set = false;        // per instantiation: more than the default 64 KB of dynamic LDS
   if (!attr_set) {
-    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK, RING>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kVmMaxLds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK>), dim3(gmain + g0 + g1 + g2), dim3(BLOCK), lds, st, h->cp, h->k1,
+  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK, RING>), dim3(gmain + g0 + g1 + g2), dim3(BLOCK), lds, st, h->cp, h->k1,
                      h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial, done,
                      fz ? *fz : VmFuse<T>{});
   MFS_LAUNCH_CHECK();
@@ -894,10 +900,14 @@ static int vcg_march_launch_blk(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double*
 template <typename T, int VEC, int WAVES, int NT, bool FUSE = false>
 static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
                                int* nparts, const VmFuse<T>* fz = nullptr) {
-  if constexpr (VEC == VecOf<T>::N && WAVES == MFS_VMARCH_MIN_WAVES)
-    if (vcg_march_block<T, VEC>(h) == 512)
-      return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512>(h, vv, ob, partial, done, st, nparts, fz);
-  return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 256>(h, vv, ob, partial, done, st, nparts, fz);
+  if constexpr (VEC == VecOf<T>::N && WAVES == MFS_VMARCH_MIN_WAVES) {
+    const int geom = vcg_march_geom<T, VEC>(h);
+    if (geom == 5124) return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512, 4>(h, vv, ob, partial, done, st, nparts, fz);
+    if constexpr (!FUSE) {
+      if (geom == 5123) return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512, 3>(h, vv, ob, partial, done, st, nparts, fz);
+    }
+  }
+  return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 256, 4>(h, vv, ob, partial, done, st, nparts, fz);
 }
 
 template <typename T, int VEC, int WAVES>
@@ -1588,6 +1598,7 @@ int mfs_vcg3d_slab_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
 
 // can the fused loop serve the engine as bound?  (the marching kernel's preconditions, 16-byte aligned CG vectors)
 static bool vcg_fuse_ok(const mfs_vcg3d* h) {
+  if ((h->dt == MFS_F32 ? vcg_march_geom<float, 4>(h) : vcg_march_geom<double, 2>(h)) % 10 == 3) return false;   // (no fused form on the 3-slot ring)
   if (!h->fuse || h->jacobi || !h->split_x || h->mask_cg || h->tiled || h->march_vec == 2 || !h->c.d || !core_vec_ok(h->c)) return false;
   return h->dt == MFS_F32 ? vcg_march_ok<float>(h, h->c.d, h->c.q) : vcg_march_ok<double>(h, h->c.d, h->c.q);
 }

@@ -96,29 +96,34 @@ def test_march_is_what_runs_by_default():
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("gres", [(12, 12, 12), (20, 24, 36), (9, 70, 16), (7, 5, 128), (10, 14, 256), (48, 80, 48), (6, 10, 512)],
                          ids=lambda g: "x".join(map(str, g)))
-def test_march_with_512_thread_workgroups(gres, dt, monkeypatch):
-    """tiles of 512 z-vectors (one workgroup of eight waves per CU: what fp64 state takes on rows too long for two 256-vector
-    rings per CU, e.g. Nz = 256) give the bits of the 256-vector tiles"""
+def test_march_geometries_give_the_same_bits(gres, dt, monkeypatch):
+    """every geometry of the marching kernel -- tiles of 256 or 512 z-vectors (512: one workgroup of eight waves per CU, what
+    long rows take), ring of 4 plane slots or 3 (a second barrier per plane: fp64 rows up to Nz = 512) -- gives the bits of
+    the one-cell-per-lane kernel"""
     sc = scenes.viscosity_scene_3d(gres, seed=7, device=DEV, noise=0.3)
     cell_vol = float(np.prod(np.array(sc["bound_size"]) / np.array(gres)))
     scale = sc["dt"] / cell_vol / sc["rho"]
     vol = sc["lvol"] / (cell_vol * 0.125)
-    outs, dqs = [], []
-    for blk in ("512", "256"):
-        monkeypatch.setenv("MFS_VISC_MARCH_BLOCK", blk)
-        eng = _engine(gres, dt, 1)
+    outs, dqs, kinds = [], [], []
+    for blk in ("scalar", "256", "512", "5123", "auto"):
+        if blk in ("scalar", "auto"):
+            monkeypatch.delenv("MFS_VISC_MARCH_BLOCK", raising=False)
+        else:
+            monkeypatch.setenv("MFS_VISC_MARCH_BLOCK", blk)
+        eng = _engine(gres, dt, 0 if blk == "scalar" else 1)
         eng.setup(scale, 37.0, sc["sphi"], vol)
         d, dv = _direction(eng, sc, seed=11)
         vecs = [eng.new_vector()[0] for _ in range(4)]
         q = vecs[3]
         q.fill_(3.0)
         eng.bind(vecs[0], vecs[1], d, vecs[2], q)
-        if eng.apply_kernel() != "march":
-            pytest.skip("rows too long for the marching kernel in this precision (fp64 at Nz = 512: one-cell-per-lane kernels)")
+        kinds.append(eng.apply_kernel())
         eng.phase_apply()
         eng.phase_reduce(0)
         torch.cuda.synchronize()
         outs.append(q.clone())
         dqs.append(float(eng.scalars[_lib.S_DQ]))
-    assert torch.equal(outs[0], outs[1]), f"max |diff| {float((outs[0] - outs[1]).abs().max())}"
-    assert abs(dqs[0] - dqs[1]) <= 1e-12 * abs(dqs[1])
+    assert kinds[0] == "scalar" and kinds[1:] == ["march"] * 4, kinds      # (a forced geometry that does not fit falls back to the automatic one)
+    for o, dq in zip(outs[1:], dqs[1:]):
+        assert torch.equal(o, outs[0]), f"max |diff| {float((o - outs[0]).abs().max())}"
+        assert abs(dq - dqs[0]) <= 1e-12 * abs(dqs[0])
