@@ -63,15 +63,24 @@ __device__ __forceinline__ Vec<T, VEC> ldv(const T* p) { return *reinterpret_cas
 
 // ---------------------------------------------------------- vector phases ---
 template <typename T, int VEC, typename F>
-__device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = false) {
+__device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = false, bool blocked = false) {
   // f(i, vec): process elements [i, i+VEC) (vec) or the single element i (tail).
   // reverse: sweep from the end of the array to its start -- consecutive CG phases
   // alternate direction so each one starts on the bytes the previous one touched
   // last (still resident in the Infinity Cache) instead of the ones it evicted first.
   const int64_t nv = n / VEC;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride)
-    f((reverse ? nv - 1 - k : k) * VEC, true);
+  if (blocked) {
+    // blocked (A/B knob MFS_REV_D=2, k_update_d only): workgroup b sweeps ONE contiguous chunk of the array instead of striding
+    // through all of it.  Same-engine A/B, viscosity CG iteration: 256^3 fp64 988.6 (strided) vs 1002.8 us, fp32 478.6 vs 500.6,
+    // 128^3 fp64 113.3 vs 114.9 -- the strided sweep stays
+    const int64_t per = (nv + gridDim.x - 1) / gridDim.x;
+    const int64_t k0 = (int64_t)blockIdx.x * per, k1 = k0 + per < nv ? k0 + per : nv;
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) f(k * VEC, true);
+  } else {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride)
+      f((reverse ? nv - 1 - k : k) * VEC, true);
+  }
   // scalar tail (n % VEC elements) handled by the first threads of block 0
   const int64_t tail = n - nv * VEC;
   if (blockIdx.x == 0 && (int64_t)threadIdx.x < tail) f(nv * VEC + threadIdx.x, false);
@@ -410,7 +419,7 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
       if (conv) return;
       d[i] = (T)((double)r[i] + beta * (double)d[i]);
     }
-  }, rev != 0);
+  }, rev == 1, rev == 2);
 }
 
 // ---- small problems: the two vector phases of an iteration in ONE launch (k_update_rdx) -----------------------------
@@ -1069,8 +1078,9 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
   if (xupd) {
 #define MFS_UD(TT, VV, NN) \
     hipLaunchKernelGGL((k_update_d<TT, VV, true, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
-                       c.hist, kHistCap, c.rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r, \
+                       c.hist, kHistCap, rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r, \
                        -(double)(c.iter_enq + 1))
+    const int rev_d = env_int("MFS_REV_D", c.rev_d);      // (read per launch: the A/B tool toggles it on one engine)
     // ... and so is r here (same-engine A/B: viscosity 256^3 632.8 -> 596.6 us/iteration, 192^3 250.0 -> 243.6)
     const int nt_r_knob = env_int("MFS_NT_RD", -1);
     const int nt_r = vec && (nt_r_knob < 0 ? 5.0 * (double)c.n * c.elt > 200e6 : nt_r_knob > 0);
