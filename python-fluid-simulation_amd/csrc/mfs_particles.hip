@@ -45,24 +45,22 @@ __device__ __forceinline__ void atomic_add_t(void* p, int dt, int64_t i, double 
   if (dt == MFS_F32) atomicAdd((float*)p + i, (float)v); else atomicAdd((double*)p + i, v);
 }
 
+// min by ONE native integer atomic instead of a compare-and-swap loop: IEEE values order like signed integers when they
+// are >= 0 and like reversed unsigned integers when they are < 0, so a non-negative candidate is a signed integer min and a
+// negative one an unsigned integer max on the same bits (either holds against a stored value of either sign: a negative
+// value has the top bit set, i.e. is below every non-negative one as a signed integer and above it as an unsigned one).
+// A plain read first: once the field has settled most candidates lose without touching the atomic unit.  The minimum does
+// not depend on the order of the candidates, so the field is bit for bit the compare-and-swap version's.
 __device__ __forceinline__ void atomic_min_t(void* p, int dt, int64_t i, double v) {
   if (dt == MFS_F32) {
-    int* a = (int*)p + i;
     const float fv = (float)v;
-    int old = *a, assumed;
-    do {
-      assumed = old;
-      if (__int_as_float(assumed) <= fv) break;
-      old = atomicCAS(a, assumed, __float_as_int(fv));
-    } while (assumed != old);
+    if (((const float*)p)[i] <= fv) return;
+    if (fv >= 0.f) atomicMin((int*)p + i, __float_as_int(fv));
+    else atomicMax((unsigned*)p + i, __float_as_uint(fv));
   } else {
-    unsigned long long* a = (unsigned long long*)p + i;
-    unsigned long long old = *a, assumed;
-    do {
-      assumed = old;
-      if (__longlong_as_double((long long)assumed) <= v) break;
-      old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-    } while (assumed != old);
+    if (((const double*)p)[i] <= v) return;
+    if (v >= 0.0) atomicMin((long long*)p + i, __double_as_longlong(v));
+    else atomicMax((unsigned long long*)p + i, (unsigned long long)__double_as_longlong(v));
   }
 }
 
