@@ -772,6 +772,7 @@ struct mfs_vcg3d {
   int march_bpc;   // its workgroups per CU (2: what its register budget makes resident)
   int march_vec;   // experiment: 2 = 8-byte vectors for fp32 state
   mfs_p2p* p2p;    // window transport of the slab loop (mfs_vcg3d_attach_p2p); null: the caller moves halos / scalars
+  int64_t last_iters;   // iterations of this engine's previous converged solve (sizes the first batch of the next one)
   int jacobi;      // 1: opt-in Jacobi-preconditioned loop (mfs_vcg3d_set_jacobi; NOT the reference's iteration)
   void* diag;      // its diagonal (n elements, built by setup when the flag is on)
   double* part_rz; // its r.z partials
@@ -1382,6 +1383,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->diag = p; p += align_up((size_t)h->n * dtype_size(dt), 4096);
   h->part_rz = (double*)p; p += align_up((size_t)kMaxPartials * 8, 4096);
   h->jacobi = env_int("MFS_VISC_JACOBI", 0);
+  h->last_iters = 0;
   h->diag_ready = false;
   h->fuse = env_int("MFS_VISC_FUSE", 0);   // measured slower than the three-launch loop: opt-in
   h->fused_run = false;
@@ -1763,13 +1765,23 @@ int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   if (int e = mfs_vcg3d_begin(h, tol, stream)) return e;
   int64_t enq = 0, iters = 0;
   int done = 0;
-  if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  // The FIRST batch is sized by the previous solve of this engine (consecutive time steps need about the same number of
+  // iterations): last count + 1/8 + 2 in one go, so that a solve normally costs ONE look at the scalar block instead of one per
+  // `check_every` iterations plus one before the loop (launches queued behind a converged iteration return at their top; a
+  // problem that starts converged is caught by them as well).  Later batches: `check_every` as before.
+  bool first = true;
   while (!done && enq < max_iter) {
-    const int64_t n = std::min(check_every, max_iter - enq);
+    int64_t n = std::min(check_every, max_iter - enq);
+    if (first && h->last_iters > 0)
+      n = std::min<int64_t>(max_iter - enq, std::min<int64_t>(h->last_iters + h->last_iters / 8 + 2, h->last_iters + 256));
+    first = false;
     if (int e = mfs_vcg3d_iterate(h, n, stream)) return e;
     if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
     enq = h->c.iter_enq;        // = enq + n, unless the poll has just taken a batch back (merged launch not resident)
   }
+  if (max_iter == 0)       // (nothing iterated: the scalar block as begin left it)
+    if (int e = mfs_vcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  if (done) h->last_iters = iters;
   if (int e = vcg_home(h, iters, done != 0, (hipStream_t)stream)) return e;
   if (iters_host) *iters_host = iters;
   return done ? MFS_OK : MFS_NOT_CONVERGED;
