@@ -85,6 +85,7 @@ struct mfs_pcg3d {
   bool book_pending;           // lean loop: the last enqueued iteration's bookkeeping has not been launched yet
   bool slab_loop;              // the running solve is the slab loop (x lives on the owned planes [1, Nx-1) only)
   int defer_x;                 // 1: native fused loop lets x += alpha d ride in the NEXT stencil launch (mfs_pcg3d_finish owes the last one)
+  int64_t last_iters;          // iterations of this engine's previous converged solve (sizes the first batch of the next one)
   int jacobi;                  // 1: opt-in Jacobi-preconditioned loop (mfs_pcg3d_set_jacobi); NOT the reference's CG
   double* part_rz;             // partial sums of r.z (Jacobi loop)
   void* zb;                    // z = r / diag as stored by the fused Jacobi loop's r update (operand of the next stencil launch)
@@ -287,6 +288,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
     h->res = res_plan(h->Nx, h->Ny, h->Nz, dt == MFS_F32 ? 4 : 2, h->c.elt, h->res_w);
   }
   h->jacobi = env_int("MFS_JACOBI", 0);
+  h->last_iters = 0;
   h->defer_x = env_int("MFS_DEFER_X", -1);
   h->x_owed = false;
   h->book_pending = false;
@@ -882,16 +884,25 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   if (int e = mfs_pcg3d_begin(h, tol, stream)) return e;
   int64_t enq = 0, iters = 0;
   int done = 0;
-  if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  // (no look at the scalar block before the loop: launches queued behind a problem that starts converged return at their top)
+  bool first = true;
   while (!done && enq < max_iter) {
     // the resident loop stops by itself inside a batch (one launch), so a longer batch costs nothing but saves the
     // launch, the reload of the state and the poll: at least 128 iterations per look there
     const int64_t every = resident_ok(h) ? std::max<int64_t>(check_every, 128) : check_every;
-    const int64_t n = std::min(every, max_iter - enq);
+    int64_t n = std::min(every, max_iter - enq);
+    // launch-per-phase loops: the FIRST batch is sized by this engine's previous solve (consecutive time steps need about the
+    // same number of iterations), so that a solve normally costs one look at the scalar block, not one per `check_every`
+    if (first && h->last_iters > 0 && !resident_ok(h))
+      n = std::min<int64_t>(max_iter - enq, std::min<int64_t>(h->last_iters + h->last_iters / 8 + 2, h->last_iters + 256));
+    first = false;
     if (int e = mfs_pcg3d_iterate(h, n, stream)) return e;
     if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
     enq = h->c.iter_enq;        // = enq + n, unless the poll has just taken a batch back (resident loop not resident)
   }
+  if (max_iter == 0)       // (nothing iterated: the scalar block as begin left it)
+    if (int e = mfs_pcg3d_poll(h, stream, &iters, &done, nullptr, nullptr, nullptr)) return e;
+  if (done) h->last_iters = iters;
   if (int e = pcg_home_d(h, iters, done != 0, (hipStream_t)stream)) return e;
   if (iters_host) *iters_host = iters;
   return done ? MFS_OK : MFS_NOT_CONVERGED;
