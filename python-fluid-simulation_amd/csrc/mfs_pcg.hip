@@ -434,6 +434,7 @@ int mfs_pcg3d_set_lean(mfs_pcg3d* h, int on) {
 
 int mfs_pcg3d_set_jacobi(mfs_pcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
+  if (h->jacobi != (on != 0)) h->last_iters = 0;      // another iteration: the previous solve predicts nothing
   h->jacobi = on != 0;
   return MFS_OK;
 }
@@ -891,9 +892,11 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
     // launch, the reload of the state and the poll: at least 128 iterations per look there
     const int64_t every = resident_ok(h) ? std::max<int64_t>(check_every, 128) : check_every;
     int64_t n = std::min(every, max_iter - enq);
-    // launch-per-phase loops: the FIRST batch is sized by this engine's previous solve (consecutive time steps need about the
-    // same number of iterations), so that a solve normally costs one look at the scalar block, not one per `check_every`
-    if (first && h->last_iters > 0 && !resident_ok(h))
+    // launch-per-phase loops, SHORT solves (up to 4 x check_every iterations, where a look at the scalar block costs as much as
+    // half a dozen iterations): the first batch is sized by this engine's previous solve -- consecutive time steps need about
+    // the same number of iterations -- so that the solve costs one look, not one per `check_every`.  (Long solves keep the
+    // fixed batches: a prediction that overshoots by hundreds of iterations costs more no-op launches than the looks it saves.)
+    if (first && h->last_iters > 0 && h->last_iters <= 4 * check_every && !resident_ok(h))
       n = std::min<int64_t>(max_iter - enq, std::min<int64_t>(h->last_iters + h->last_iters / 8 + 2, h->last_iters + 256));
     first = false;
     if (int e = mfs_pcg3d_iterate(h, n, stream)) return e;

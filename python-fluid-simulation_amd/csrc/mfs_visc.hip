@@ -1765,14 +1765,15 @@ int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   if (int e = mfs_vcg3d_begin(h, tol, stream)) return e;
   int64_t enq = 0, iters = 0;
   int done = 0;
-  // The FIRST batch is sized by the previous solve of this engine (consecutive time steps need about the same number of
-  // iterations): last count + 1/8 + 2 in one go, so that a solve normally costs ONE look at the scalar block instead of one per
-  // `check_every` iterations plus one before the loop (launches queued behind a converged iteration return at their top; a
-  // problem that starts converged is caught by them as well).  Later batches: `check_every` as before.
+  // SHORT solves (up to 4 x check_every iterations): the first batch is sized by the previous solve of this engine
+  // (consecutive time steps need about the same number of iterations): last count + 1/8 + 2 in one go, so that the solve costs
+  // ONE look at the scalar block instead of one per `check_every` iterations (launches queued behind a converged iteration
+  // return at their top; a problem that starts converged is caught by them as well).  Later batches, and long solves --
+  // where an overshooting prediction costs more no-op launches than the looks it saves --: `check_every` as before.
   bool first = true;
   while (!done && enq < max_iter) {
     int64_t n = std::min(check_every, max_iter - enq);
-    if (first && h->last_iters > 0)
+    if (first && h->last_iters > 0 && h->last_iters <= 4 * check_every)
       n = std::min<int64_t>(max_iter - enq, std::min<int64_t>(h->last_iters + h->last_iters / 8 + 2, h->last_iters + 256));
     first = false;
     if (int e = mfs_vcg3d_iterate(h, n, stream)) return e;
@@ -1816,6 +1817,7 @@ int mfs_vcg3d_loop_info(mfs_vcg3d* h) {
 // OPT-IN Jacobi preconditioning of mfs_vcg3d_begin / iterate / solve (default off; env MFS_VISC_JACOBI=1): see mfs.h
 int mfs_vcg3d_set_jacobi(mfs_vcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
+  if (h->jacobi != (on ? 1 : 0)) h->last_iters = 0;      // another iteration: the previous solve predicts nothing
   h->jacobi = on ? 1 : 0;
   return MFS_OK;
 }
