@@ -175,8 +175,10 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
                          dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done,                 \
                          (const T*)fz->r, (const T*)fz->d_old, (T*)fz->d_new, (const double*)nullptr, cz2,             \
                          (T*)fz->xdef, (const double*)nullptr, bk)
-      if (fz->xdef) {
-        MFS_REQUIRE(!asym, "the deferred x update is for the symmetric operator");
+      if (fz->xdef && asym) {      // (the density operator's -z tap and the deferred x update are independent of each other)
+        if (comp) { if (nt) MFS_GO_B(7, true, true, true); else MFS_GO_B(0, true, true, true); }
+        else      { if (nt) MFS_GO_B(7, false, true, true); else MFS_GO_B(0, false, true, true); }
+      } else if (fz->xdef) {
         if (comp) { if (nt) MFS_GO_B(7, true, false, true); else MFS_GO_B(0, true, false, true); }
         else      { if (nt) MFS_GO_B(7, false, false, true); else MFS_GO_B(0, false, false, true); }
       } else if (asym) {
@@ -187,18 +189,23 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
         else      { if (nt) MFS_GO_B(7, false, false, false); else MFS_GO_B(0, false, false, false); }
       }
 #undef MFS_GO_B
-    } else if (asym) {
-      if (fz) MFS_GO_NT_CMP(true, 1, true); else MFS_GO_NT_CMP(false, 1, true);
     } else if (fz && fz->xdef) {
-      // fused direction update + the previous iteration's x update (PD 1 only)
-#define MFS_GO_X(NTV, CMP)                                                                                             \
-      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, false, true>), dim3(grid), dim3(kApplyBlock), \
+      // fused direction update + the previous iteration's x update (PD 1 only); symmetric or density operator
+#define MFS_GO_X(NTV, CMP, ASY)                                                                                        \
+      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, true>), dim3(grid), dim3(kApplyBlock), \
                          lds, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)fz->r, (const T*)fz->d_old, \
                          (T*)fz->d_new, (const double*)(h->c.scal + S_BETA), cz2, (T*)fz->xdef,                          \
                          (const double*)(h->c.scal + S_ALPHA))
-      if (comp) { if (nt) MFS_GO_X(7, true); else MFS_GO_X(0, true); }
-      else      { if (nt) MFS_GO_X(7, false); else MFS_GO_X(0, false); }
+      if (asym) {
+        if (comp) { if (nt) MFS_GO_X(7, true, true); else MFS_GO_X(0, true, true); }
+        else      { if (nt) MFS_GO_X(7, false, true); else MFS_GO_X(0, false, true); }
+      } else {
+        if (comp) { if (nt) MFS_GO_X(7, true, false); else MFS_GO_X(0, true, false); }
+        else      { if (nt) MFS_GO_X(7, false, false); else MFS_GO_X(0, false, false); }
+      }
 #undef MFS_GO_X
+    } else if (asym) {
+      if (fz) MFS_GO_NT_CMP(true, 1, true); else MFS_GO_NT_CMP(false, 1, true);
     } else if (fz) {
       if (pd == 2) MFS_GO_NT_CMP(true, 2, false); else MFS_GO_NT_CMP(true, 1, false);
     } else if (comp || nt == 0 || nt == 7) {
@@ -572,12 +579,12 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
 static bool native_fuse_ok(const mfs_pcg3d* h);
 static bool jac_fuse_ok(const mfs_pcg3d* h);
 static bool resident_ok(const mfs_pcg3d* h);
-// deferred x update: fused native loop, symmetric operator, prefetch depth 1, x 16-byte aligned
+// deferred x update: fused native loop (symmetric or density operator), prefetch depth 1, x 16-byte aligned
 static bool xdef_ok(const mfs_pcg3d* h) {
   // auto (< 0): on once the CG vectors no longer fit the Infinity Cache (256^3 fp32: 134.7 -> 130.2 us/iteration,
   // fp64: 295 -> 276); below that the extra streams cost the march more than the update kernel saves (128^3: +4 %)
   const bool on = h->defer_x < 0 ? (5.0 * (double)h->n * h->c.elt > 200e6) : (h->defer_x != 0);
-  return on && (native_fuse_ok(h) || jac_fuse_ok(h)) && !h->asym && h->pd < 2 && ((uintptr_t)h->c.x % 16 == 0);
+  return on && (native_fuse_ok(h) || jac_fuse_ok(h)) && h->pd < 2 && ((uintptr_t)h->c.x % 16 == 0);
 }
 
 // the fused stencil launch can serve the engine as bound (LDS march, whole 16-byte vectors, aligned CG vectors)

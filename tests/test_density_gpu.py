@@ -103,6 +103,39 @@ def test_class_solve_matches_reference(name):
     np.testing.assert_allclose(N(px), g["out_px"], rtol=0, atol=1e-6 * np.abs(g["out_px"] - g["px"]).max() + 1e-7)
 
 
+@pytest.mark.parametrize("name", ["d3d_c_20", "d3d_a_12"])
+@pytest.mark.parametrize("jacobi", [False, True], ids=["reference_cg", "jacobi"])
+def test_deferred_x_update_with_the_density_operator(name, jacobi):
+    """the x update deferred into the next stencil launch (its default beyond the Infinity Cache, forced here) with the
+    density operator's asymmetric -z tap: the same history, solution and vectors, bit for bit, as with the update in the vector
+    phase -- on the engine, from the golden's stored right-hand side (two `solve`s of the class differ in the last bits of
+    their RHS: the particle splat adds with fp atomics in arbitrary order); launch-per-phase loops (the resident small-grid
+    loop carries x in registers anyway)"""
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    outs = []
+    for defer in (True, False):
+        eng = PcgEngine(gres, torch.float64, DEV)
+        eng.setup_density(T(g["lphi"]), T(g["wx"]), T(g["wy"]), T(g["wz"]))
+        eng.set_resident(False)
+        eng.set_defer_x(defer)
+        eng.set_jacobi(jacobi)
+        b = T(g["b"]).clone()
+        x, d, r, q = (torch.zeros(gres, dtype=torch.float64, device=DEV) for _ in range(4))
+        eng.bind(b, x, d, r, q)
+        info = eng.loop_info()
+        assert info["deferred_x_update"] == defer and info["jacobi"] == jacobi and not info["resident"], info
+        ok, it = eng.solve(float(g["tol"]), int(np.prod(gres)), 8)
+        assert ok
+        outs.append((it, eng.history(), x.clone(), d.clone(), r.clone()))
+    assert outs[0][0] == outs[1][0]
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for a, bb in zip(outs[0][2:], outs[1][2:]):
+        assert torch.equal(a, bb)
+    if not jacobi:
+        np.testing.assert_allclose(N(outs[0][2]), g["x"], rtol=0, atol=1e-6 * np.abs(g["x"]).max())
+
+
 def test_density_weights_feed_the_pressure_solve():
     """the notebook's hand-over (ipynb:4590 -> :4648): PressureSolver.solve(..., wx=DensitySolver.wx, ...)"""
     from solver.PressureCGSolver3D import PressureCGSolver3D
@@ -119,13 +152,16 @@ def test_density_weights_feed_the_pressure_solve():
 
 
 @pytest.mark.parametrize("name,world,transport", [("d3d_a_12", 2, "p2p"), ("d3d_a_12", 3, "p2p"), ("d3d_b_10x12x14_f32", 2, "p2p"),
-                                                  ("d3d_a_12", 2, "rccl")])
+                                                  ("d3d_a_12", 2, "rccl"), ("d3d_c_20", 2, "p2p+defer_x")])
 def test_slab_density_solver_matches_reference(name, world, transport, tmp_path):
     """SlabDensityCGSolver3D (replicated particles, CG loop slab-decomposed over `world` processes sharing the GPU):
     history, solution, displacements and moved particles against the goldens of the reference's own solve."""
     from test_p2p_gpu import _run_ranks
     g = golden(name)
-    res = _run_ranks(name, world, tmp_path, "f64", P2P_TEST_MODE="density", P2P_TEST_TRANSPORT=transport)
+    extra = {}
+    if transport.endswith("+defer_x"):       # the window slab loop with the x update deferred into the edge / interior launches
+        transport, extra = "p2p", {"MFS_DEFER_X": "1"}
+    res = _run_ranks(name, world, tmp_path, "f64", P2P_TEST_MODE="density", P2P_TEST_TRANSPORT=transport, **extra)
     for r in res:
         assert str(r["transport"]) == transport
         h = r["hist"]
