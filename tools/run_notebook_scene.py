@@ -42,4 +42,9 @@ its = np.array(its)
 print(json.dumps({"scene": "notebook code cell 9 (48x80x48, %d particles)" % sim.particle.num_particles, "steps": steps,
                   "s_per_step": round(t / steps, 4), "stage_ms_per_step": {k: round(v / steps * 1e3, 3) for k, v in tim.items()},
                   "mean_cg_iterations(density,viscosity,pressure)": [round(float(v), 1) for v in its.mean(axis=0)],
+                  "max_cg_iterations": [int(v) for v in its.max(axis=0)],
+                  "particles_after": {"mean": [round(float(v), 5) for v in sim.particle.x.mean(dim=0)],
+                                      "min": [round(float(v), 5) for v in sim.particle.x.min(dim=0).values],
+                                      "max": [round(float(v), 5) for v in sim.particle.x.max(dim=0).values],
+                                      "speed_max": round(float(sim.particle.v.norm(dim=1).max()), 4)},
                   "reference_context": "committed notebook output on a GeForce: press 0.745 s, visco (U-Net) 0.88 s, p2g 6.2 ms per step"}))
