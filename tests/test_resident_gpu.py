@@ -196,3 +196,32 @@ def test_a_launch_that_is_not_fully_resident_falls_back(monkeypatch):
     np.testing.assert_array_equal(got["hist"], ref["hist"])
     for k in ("x", "d", "r", "q"):
         assert torch.equal(got[k], ref[k]), k
+
+
+@pytest.mark.parametrize("jacobi", [False, True], ids=["reference_cg", "jacobi"])
+def test_resident_loop_with_the_density_operator(jacobi):
+    """the density operator's asymmetric -z tap inside the resident launch (template flags ASYM x JAC), from a golden's stored
+    right-hand side, against the launch-per-phase loop of the same engine settings"""
+    from conftest import golden
+    from mfs.pcg import PcgEngine
+    g = golden("d3d_c_20")
+    gres = tuple(int(v) for v in g["gres"])
+    outs = []
+    for resident in (True, False):
+        eng = PcgEngine(gres, torch.float64, DEV)
+        eng.setup_density(T(g["lphi"]), T(g["wx"]), T(g["wy"]), T(g["wz"]))
+        eng.set_resident(resident)
+        eng.set_jacobi(jacobi)
+        b = T(g["b"]).clone()
+        x, d, r, q = (torch.zeros(gres, dtype=torch.float64, device=DEV) for _ in range(4))
+        eng.bind(b, x, d, r, q)
+        info = eng.loop_info()
+        assert info["resident"] == resident and info["jacobi"] == jacobi, info
+        ok, it = eng.solve(float(g["tol"]), int(np.prod(gres)), 8)
+        assert ok
+        outs.append((it, np.array(eng.history()), x.clone()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1
+    n = min(len(outs[0][1]), len(outs[1][1]), 41)
+    np.testing.assert_allclose(outs[0][1][:n], outs[1][1][:n], rtol=1e-9)
+    scale = float(outs[1][2].abs().max())
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-6 * scale
