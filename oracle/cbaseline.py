@@ -21,6 +21,8 @@ def _load():
         lib = C.CDLL(_SO)
         lib.mfs_oracle_threads.restype = C.c_int
         lib.mfs_oracle_set_threads.argtypes = [C.c_int]
+        lib.mfs_oracle_set_variant.restype = None
+        lib.mfs_oracle_set_variant.argtypes = [C.c_int, C.c_int]
         lib.mfs_oracle_pressure_apply3d.restype = None
         lib.mfs_oracle_pressure_apply3d.argtypes = [C.POINTER(C.c_int64), _pd, _pd, _pd, _pd, _pd, _pd]
         lib.mfs_oracle_pressure_cg3d.restype = C.c_int64
@@ -48,6 +50,13 @@ def available():
 
 def threads():
     return int(_load().mfs_oracle_threads())
+
+
+def set_variant(dot_variant=0, fma_mask=0):
+    """rounding variant of the C oracle (mfs_oracle_set_variant): dot_variant 0..15 permutes the summation order of the dot
+    products, fma_mask bit 0 / 1 / 2 fuses the multiply-adds of the dots / the vector updates / the operator.  (0, 0) is the
+    oracle proper; the others are the same algorithm with different rounding (tests/test_history_envelope.py)."""
+    _load().mfs_oracle_set_variant(int(dot_variant), int(fma_mask))
 
 
 def _g(gres):

@@ -17,6 +17,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -38,6 +39,14 @@ void mfs_oracle_set_threads(int n) {
 #endif
 }
 
+/* ---- rounding variants (tests/test_history_envelope.py: how far does the residual history move when ONLY rounding
+ * changes?).  Variant 0 is the oracle proper.  `dot_variant` permutes the summation order of the dot products,
+ * `fma_mask` fuses multiply-adds: bit 0 in the dot products, bit 1 in the x / r / d updates, bit 2 in the operator's
+ * accumulation.  Every variant is the reference's algorithm statement for statement; they differ in rounding only. */
+static int g_dot_variant = 0, g_fma_mask = 0;
+void mfs_oracle_set_variant(int dot_variant, int fma_mask) { g_dot_variant = dot_variant; g_fma_mask = fma_mask; }
+#define MADD(bit, a, b, c) ((g_fma_mask & (bit)) ? fma((a), (b), (c)) : (a) * (b) + (c))
+
 static inline double theta(double phi, double nphi) { /* :75  min(1, max(0.01, phi/(phi-nphi))) */
   double f = phi / (phi - nphi);
   if (f < 0.01) f = 0.01;
@@ -58,7 +67,7 @@ void mfs_oracle_pressure_apply3d(const int64_t g[3], const double* v, double* ou
         double val = 0.0, diag = 0.0, nphi, w;
 #define TAP(NB, W)                                   \
   nphi = lphi[NB]; w = (W);                          \
-  if (nphi < 0) { val -= w * v[NB]; diag += w; }     \
+  if (nphi < 0) { val = MADD(4, -w, v[NB], val); diag += w; }     \
   else { diag += w / theta(phi, nphi); }
         TAP(c + Ny * Nz, wx[((x + 1) * Ny + y) * Nz + z])          /* +x :68-76 */
         TAP(c - Ny * Nz, wx[(x * Ny + y) * Nz + z])                /* -x */
@@ -67,15 +76,53 @@ void mfs_oracle_pressure_apply3d(const int64_t g[3], const double* v, double* ou
         TAP(c + 1, wz[(x * Ny + y) * (Nz + 1) + z + 1])            /* +z */
         TAP(c - 1, wz[(x * Ny + y) * (Nz + 1) + z])                /* -z */
 #undef TAP
-        val += diag * v[c];                                        /* :128 */
+        val = MADD(4, diag, v[c], val);                            /* :128 */
         out[c] = val;
       }
 }
 
-static double dot(const double* a, const double* b, int64_t n) {
+/* Dot product with a FIXED summation order, whatever the thread count: partial sums over blocks of consecutive
+ * products, then the partials added in block order (round 2's `omp reduction` combined the threads' sums in arrival
+ * order -- the history, and with it a test, changed with OMP_NUM_THREADS).  Variants permute the order (see above). */
+static double block_sum(const double* a, const double* b, int64_t lo, int64_t hi, int variant) {
+  const int f = g_fma_mask & 1;
+  if (variant == 3) {                                   /* backwards inside the block */
+    double s = 0.0;
+    for (int64_t i = hi - 1; i >= lo; --i) s = f ? fma(a[i], b[i], s) : s + a[i] * b[i];
+    return s;
+  }
+  if (variant == 5) {                                   /* four interleaved chains (a vector unit's order) */
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = lo; i < hi; ++i) s4[(i - lo) & 3] = f ? fma(a[i], b[i], s4[(i - lo) & 3]) : s4[(i - lo) & 3] + a[i] * b[i];
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
+  if (variant == 7) {                                   /* extended-precision accumulator */
+    long double s = 0.0L;
+    for (int64_t i = lo; i < hi; ++i) s += (long double)a[i] * (long double)b[i];
+    return (double)s;
+  }
   double s = 0.0;
-#pragma omp parallel for reduction(+ : s) schedule(static)
-  for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+  for (int64_t i = lo; i < hi; ++i) s = f ? fma(a[i], b[i], s) : s + a[i] * b[i];
+  return s;
+}
+
+static double dot(const double* a, const double* b, int64_t n) {
+  static const int64_t kBlock[8] = {4096, 1024, 16384, 4096, 4096, 4096, 333, 4096};
+  const int variant = g_dot_variant & 7;
+  const int64_t B = kBlock[variant];
+  const int64_t nb = (n + B - 1) / B;
+  double stack_part[1024];
+  double* part = nb <= 1024 ? stack_part : (double*)malloc((size_t)nb * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < nb; ++k) part[k] = block_sum(a, b, k * B, (k + 1) * B < n ? (k + 1) * B : n, variant);
+  double s = 0.0;
+  if (variant == 4) { for (int64_t k = nb - 1; k >= 0; --k) s += part[k]; }           /* partials in reverse */
+  else if (g_dot_variant & 8) {                                                       /* pairwise tree over the partials */
+    for (int64_t w = 1; w < nb; w *= 2)
+      for (int64_t k = 0; k + w < nb; k += 2 * w) part[k] += part[k + w];
+    s = nb ? part[0] : 0.0;
+  } else { for (int64_t k = 0; k < nb; ++k) s += part[k]; }
+  if (part != stack_part) free(part);
   return s;
 }
 
@@ -102,14 +149,14 @@ int64_t mfs_oracle_pressure_cg3d(const int64_t g[3], const double* b, double* x,
       const double dq = dot(d, q, n);
       const double alpha = delta / dq;                             /* :211 */
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < n; ++i) { x[i] += alpha * d[i]; r[i] -= alpha * q[i]; }  /* :212-213 */
+      for (int64_t i = 0; i < n; ++i) { x[i] = MADD(2, alpha, d[i], x[i]); r[i] = MADD(2, -alpha, q[i], r[i]); }  /* :212-213 */
       const double old_delta = delta;
       delta = dot(r, r, n);                                        /* :216 */
       if (history && hn + 1 < hist_cap) { history[hn++] = dq; history[hn++] = delta; }
       if (delta < tol * tol) { conv = 1; break; }                  /* :218 */
       const double beta = delta / old_delta;                       /* :220 */
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < n; ++i) d[i] = r[i] + beta * d[i];   /* :221 */
+      for (int64_t i = 0; i < n; ++i) d[i] = MADD(2, beta, d[i], r[i]);   /* :221 */
     }
     if (!conv) it = max_iter;
   }
@@ -184,7 +231,7 @@ void mfs_oracle_visc_apply3d(const int64_t g[3], double scale, double mu, const 
             const double k = tp.fac == 2 ? 2 * scale * mu : scale * mu;
             const int64_t* ss = sh[tp.comp];
             const double nb = v[tp.comp][((x + tp.dx) * ss[1] + (y + tp.dy)) * ss[2] + (z + tp.dz)];
-            val += tp.sgn * (k * vs[tp.vol] * nb);
+            val = MADD(4, tp.sgn * (k * vs[tp.vol]), nb, val);
           }
 #undef DG
           o[c][i] = val;
@@ -221,14 +268,14 @@ int64_t mfs_oracle_visc_cg3d(const int64_t g[3], double scale, double mu, const 
       const double dq = DOT3(d, q);                                             /* :592 */
       const double alpha = delta / dq;                                          /* :594 */
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < n; ++i) { x[i] += alpha * d[i]; r[i] -= alpha * q[i]; }   /* :595-601 */
+      for (int64_t i = 0; i < n; ++i) { x[i] = MADD(2, alpha, d[i], x[i]); r[i] = MADD(2, -alpha, q[i], r[i]); }   /* :595-601 */
       const double old_delta = delta;
       delta = DOT3(r, r);                                                       /* :604 */
       if (history && hn + 1 < hist_cap) { history[hn++] = dq; history[hn++] = delta; }
       if (delta < tol * tol) { conv = 1; break; }                               /* :605 */
       const double beta = delta / old_delta;                                    /* :607 */
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < n; ++i) d[i] = r[i] + beta * d[i];                /* :608-610 */
+      for (int64_t i = 0; i < n; ++i) d[i] = MADD(2, beta, d[i], r[i]);                /* :608-610 */
     }
     if (!conv) it = max_iter;
   }

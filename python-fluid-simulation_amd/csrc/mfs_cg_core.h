@@ -458,7 +458,9 @@ __global__ void __launch_bounds__(kRdxBlock)
 k_update_rdx(T* __restrict__ x, T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
              double* __restrict__ scal, int par, const double* __restrict__ part_dq, int npart, RdxArgs a) {
   typedef vec_t<T, VEC> V;
-  const double dn = scal[S_DONE];
+  // agent-scope load (sc1, from L2): a workgroup scheduled LATE -- after the others of this launch timed out on its
+  // missing record and raised the flag -- must see it; a plain load may be served by a line another XCD's L2 still holds
+  const double dn = __hip_atomic_load(scal + S_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const double delta = scal[S_RING + par], tol2 = scal[S_TOL2];
   const int64_t nv = n / VEC;
   const int64_t stride = (int64_t)kRdxW * kRdxBlock;
@@ -548,11 +550,20 @@ k_update_rdx(T* __restrict__ x, T* __restrict__ d, T* __restrict__ r, const T* _
   __syncthreads();
   if (!s_ok) {       // not all workgroups are resident: nothing has been written; say so and stop the batch
     if (threadIdx.x == 0) {
+      // withdraw the own record (tag 0 is never a launch's tag): a workgroup that arrives after this one has left must
+      // not find a complete table and carry the episode through on its own chunk -- it times out clean like everybody else
+      unsigned long long* g = a.rec + (size_t)blockIdx.x * kRdxRecStride;
+      rdx_u64x2 w;
+      w[0] = 0ull; w[1] = 0ull;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(g), "v"(w) : "memory");
       __hip_atomic_store(scal + S_ERR, (double)kErrNotResident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(scal + S_DONE, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
+  // a complete table and a raised flag cannot both be this launch's (whoever raised it withdrew a record first); checked
+  // once more before the first store all the same: the flag is the contract "nothing written" rests on
+  if (__hip_atomic_load(scal + S_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) return;
   const double rr = s_rr;
   const bool conv = rr < tol2;
   const double beta = rr / delta;
@@ -950,6 +961,11 @@ struct CgCore {
   unsigned long long* rdx_rec = nullptr;
   unsigned rdx_tag = 0;
   int rdx = 1;
+  // knobs read ONCE, at engine creation (never per launch: the loop is tuned at the microsecond level, and a test hook
+  // must not be switchable under a running solve)
+  unsigned long long rdx_timeout_ticks = 25000000ull;   // MFS_RDX_TIMEOUT_MS (wall clock, 100 MHz)
+  int rdx_drop_wg = -1;                                 // MFS_RDX_TEST_DROP_WG: fault injection, tests only
+  int nt_q = -1, nt_rd = -1;                            // MFS_NT_Q, MFS_NT_RD (A/B: -1 auto by size)
 };
 
 static inline size_t core_ws_bytes() {
@@ -983,6 +999,10 @@ static inline int core_init(CgCore& c, int dt, int64_t n) {
   c.rev_xr = env_int("MFS_REV_XR", 0);
   c.rev_d = env_int("MFS_REV_D", 0);
   c.rdx = env_int("MFS_RDX", 1);
+  c.rdx_timeout_ticks = (unsigned long long)std::max(1, env_int("MFS_RDX_TIMEOUT_MS", 250)) * 100000ull;
+  c.rdx_drop_wg = env_int("MFS_RDX_TEST_DROP_WG", -1);
+  c.nt_q = env_int("MFS_NT_Q", -1);
+  c.nt_rd = env_int("MFS_NT_RD", -1);
   if (hipHostMalloc((void**)&c.pinned, MFS_PCG_NSCALARS * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     set_error("hipHostMalloc for the poll buffer failed");
     return MFS_E_HIP;
@@ -1058,8 +1078,8 @@ static inline int core_update_xr(CgCore& c, bool fold, hipStream_t st, int mode 
   if (mode == 1) {
     // r-only form: the flag streams q.  Pays only when one vector is far beyond what the Infinity Cache keeps between
     // the apply and this kernel (A/B: viscosity 256^3, 201 MB vectors, 642 -> 631 us/iteration; pressure 256^3, 67 MB
-    // vectors, 125.0 -> 127.9 us: q is still on-die there).  MFS_NT_Q = 0 / 1 overrides (read per launch).
-    const int knob = env_int("MFS_NT_Q", -1);
+    // vectors, 125.0 -> 127.9 us: q is still on-die there).  MFS_NT_Q = 0 / 1 overrides (read at engine creation).
+    const int knob = c.nt_q;
     ntx = knob < 0 ? ((double)c.n * c.elt > 128e6) : (knob != 0);
   }
   if (mode == 1) { MFS_XR_MODE(1) } else if (mode == 2) { MFS_XR_MODE(2) } else { MFS_XR_MODE(0) }
@@ -1080,14 +1100,13 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
     hipLaunchKernelGGL((k_update_d<TT, VV, true, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
                        c.hist, kHistCap, rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r, \
                        -(double)(c.iter_enq + 1))
-    const int rev_d = env_int("MFS_REV_D", c.rev_d);      // (read per launch: the A/B tool toggles it on one engine)
+    const int rev_d = c.rev_d;
     // ... and so is r here (same-engine A/B: viscosity 256^3 632.8 -> 596.6 us/iteration, 192^3 250.0 -> 243.6)
-    const int nt_r_knob = env_int("MFS_NT_RD", -1);
+    const int nt_r_knob = c.nt_rd;
     const int nt_r = vec && (nt_r_knob < 0 ? 5.0 * (double)c.n * c.elt > 200e6 : nt_r_knob > 0);
     // x is touched once per iteration: streamed past the caches once the five vectors exceed the Infinity Cache
     // (same-engine A/B, tools/visc_ab.py: viscosity 256^3 614 -> 589 us/iteration, 192^3 242.6 -> 237.0, 128^3 neutral).
-    // Read per launch so that the A/B tool can toggle it on one engine.
-    const int nt_knob = env_int("MFS_NT_XD", c.nt_xd);
+    const int nt_knob = c.nt_xd;
     const bool ntx = vec && (nt_knob < 0 ? 5.0 * (double)c.n * c.elt > 200e6 : nt_knob > 0);
     if (c.dt == MFS_F32) { if (!vec) MFS_UD(float, 1, false); else if (ntx) MFS_UD(float, 4, true); else MFS_UD(float, 4, false); }
     else                 { if (!vec) MFS_UD(double, 1, false); else if (ntx) MFS_UD(double, 2, true); else MFS_UD(double, 2, false); }
@@ -1124,8 +1143,7 @@ static inline int core_update_rdx(CgCore& c, hipStream_t st) {
     MFS_HIP_TRY(hipMemsetAsync(c.rdx_rec, 0, (size_t)kRdxW * kRdxRecStride * 8, st));
     c.rdx_tag = 0;
   }
-  RdxArgs a{c.rdx_rec, ++c.rdx_tag, (unsigned long long)std::max(1, env_int("MFS_RDX_TIMEOUT_MS", 250)) * 100000ull,
-            env_int("MFS_RDX_TEST_DROP_WG", -1), c.hist, kHistCap};
+  RdxArgs a{c.rdx_rec, ++c.rdx_tag, c.rdx_timeout_ticks, c.rdx_drop_wg, c.hist, kHistCap};
   const int par = (int)(c.iter_enq & 1);
 #define MFS_RDX_GO(TT, VV, KK) \
   hipLaunchKernelGGL((k_update_rdx<TT, VV, KK>), dim3(kRdxW), dim3(kRdxBlock), 0, st, (TT*)c.x, (TT*)c.d, (TT*)c.r, (const TT*)c.q, \

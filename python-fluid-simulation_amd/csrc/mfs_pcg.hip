@@ -101,6 +101,9 @@ struct mfs_pcg3d {
   ResPlan res;                 // decomposition (res.ok false: the grid does not qualify)
   u64 *res_ar, *res_mirror;    // granule table of the dot products / mirror of the box faces of r (workspace)
   unsigned res_epoch;          // episode tags handed out so far (monotonic over the engine's life)
+  // read once at creation (never per batch): record stride, the two spin bounds (wall clock, 100 MHz), fault injection
+  int res_rec_stride, res_drop_wg;
+  unsigned long long res_timeout_ticks, res_first_timeout_ticks;
   int compress;                // 1: per-iteration kernel skips the coefficient arrays of ZERO / REGULAR vectors
   int grid_apply, cus;
   int variant, xchunk, nt, bpc, nt_auto;   // apply-kernel tuning (mfs_pcg3d_tune)
@@ -286,6 +289,10 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->part_rz = (double*)(p + 7 * cs + align_up((size_t)h->n, 4096));
   h->resident = env_int("MFS_RESIDENT", -1);
   h->res_w = std::max(1, std::min(kResMaxW, env_int("MFS_RES_W", 64)));
+  h->res_rec_stride = std::max(2, std::min(kResRecStrideMax, env_int("MFS_RES_REC_STRIDE", 64) & ~1));   // u64 words between records (512 B: one record per memory line pair; 16-byte stride costs 0.4 us per iteration)
+  h->res_timeout_ticks = (unsigned long long)std::max(1, env_int("MFS_RES_TIMEOUT_MS", 2000)) * 100000ull;
+  h->res_first_timeout_ticks = (unsigned long long)std::max(1, env_int("MFS_RES_FIRST_TIMEOUT_MS", 250)) * 100000ull;
+  h->res_drop_wg = env_int("MFS_RES_TEST_DROP_WG", -1);      // tests only
   h->res = ResPlan{};
   h->res_ar = nullptr; h->res_mirror = nullptr; h->res_epoch = 0;
   if (res_ws_bytes(h->n, h->c.elt) > 0) {
@@ -765,11 +772,11 @@ static int pcg_iterate_resident(mfs_pcg3d* h, int64_t n, hipStream_t st) {
     a.scal = h->c.scal; a.hist = h->c.hist; a.hist_cap = kHistCap;
     a.j0 = h->c.iter_enq; a.n_iter = nb;
     a.ar = h->res_ar; a.mirror = h->res_mirror;
-    a.rec_stride = std::max(2, std::min(kResRecStrideMax, env_int("MFS_RES_REC_STRIDE", 64) & ~1));   // u64 words between records (512 B: one record per memory line pair; 16-byte stride costs 0.4 us per iteration)
+    a.rec_stride = h->res_rec_stride;
     a.tag0 = h->res_epoch + 1u;
-    a.timeout_ticks = (u64)std::max(1, env_int("MFS_RES_TIMEOUT_MS", 2000)) * 100000ull;   // wall clock: 100 MHz
-    a.first_timeout_ticks = (u64)std::max(1, env_int("MFS_RES_FIRST_TIMEOUT_MS", 250)) * 100000ull;
-    a.test_drop_wg = env_int("MFS_RES_TEST_DROP_WG", -1);
+    a.timeout_ticks = h->res_timeout_ticks;
+    a.first_timeout_ticks = h->res_first_timeout_ticks;
+    a.test_drop_wg = h->res_drop_wg;
     int e = h->dt == MFS_F32 ? pcg_launch_resident<float, 4>(h, a, st) : pcg_launch_resident<double, 2>(h, a, st);
     if (e) return e;
     h->res_epoch += per_it * (unsigned)nb;

@@ -271,7 +271,9 @@ template <typename T, int VEC, int KV, bool ASYM, bool JAC = false>
 __global__ void __launch_bounds__(kResBlock, 2)
 k_pcg_resident(ResArgs a) {
   double* const scal = a.scal;
-  if (scal[S_DONE] != 0.0) return;                       // raised before this launch: uniform over the grid
+  // raised before this launch: uniform over the grid.  Agent-scope load: a workgroup scheduled after others of this launch
+  // gave up must see THEIR flag too (a plain load may hit a stale line in this XCD's L2)
+  if (__hip_atomic_load(scal + S_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) return;
   if ((int)blockIdx.x == a.test_drop_wg) return;
   extern __shared__ __align__(16) unsigned char res_smem[];
   T* const img = reinterpret_cast<T*>(res_smem);

@@ -190,15 +190,25 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C python-fluid-simulation_amd/csrc`). "
             "There is no CPU fallback for the solver path.")
     lib = C.CDLL(LIB_PATH)
+    lib.mfs_abi_version.restype = _i
+    lib.mfs_abi_version.argtypes = []
+    v = lib.mfs_abi_version()
+    # an older A/B build (tools/ab_libs.sh) may be loaded through MFS_LIB, but only on request: MFS_LIB_ALLOW_OLD_ABI=1
+    # skips the version check and leaves entry points the build lacks untyped (calling one raises AttributeError)
+    allow_old = bool(os.environ.get("MFS_LIB")) and os.environ.get("MFS_LIB_ALLOW_OLD_ABI") == "1"
+    if v != ABI_VERSION and not allow_old:
+        raise ImportError(f"{LIB_PATH}: ABI {v} != binding ABI {ABI_VERSION}; rebuild (`make -C python-fluid-simulation_amd/csrc`)"
+                          + ("; MFS_LIB points at a stale build (MFS_LIB_ALLOW_OLD_ABI=1 loads it anyway, for A/B tools)"
+                             if os.environ.get("MFS_LIB") else ""))
+    missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+    if missing and not allow_old:
+        raise ImportError(f"{LIB_PATH} lacks {len(missing)} declared entry points ({', '.join(missing[:4])}, ...); rebuild")
     for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("MFS_LIB") and not hasattr(lib, name):
-            continue                     # an older A/B build of the ABI (tools/, MFS_LIB only): newer entry points absent
-        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        if name in missing:
+            continue
+        fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    v = lib.mfs_abi_version()
-    if v != ABI_VERSION:
-        raise ImportError(f"libmfs_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

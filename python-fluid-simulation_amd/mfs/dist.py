@@ -43,6 +43,17 @@ def collective_timeout_s():
     return float(os.environ.get("MFS_COLLECTIVE_TIMEOUT_S", "60"))
 
 
+def coll_device(dist, group, device):
+    """where the operands of a small host-side collective (counts, a CFL maximum, gathered particle tables) must live:
+    an "nccl" (RCCL) group has no CPU backend -- `dist.all_reduce(cpu_tensor)` raises "No backend type associated with
+    device type cpu" -- so they go to the rank's GPU and come back with .cpu(); every other backend (gloo: CPU tests,
+    one-GPU rehearsals) takes host tensors"""
+    import torch
+    if dist.get_backend(group) == "nccl":
+        return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def pg_timeout():
     """`timeout=` for init_process_group in the launchers (bench.py, tools, test workers): the backend's own bound
     (gloo: every blocking call; nccl: the watchdog that aborts a communicator whose collective never completes)"""
@@ -467,6 +478,42 @@ class SlabBands:
         self.cuts = [0] + [SlabPartition(nx, self.world, r).owned[0] for r in range(1, self.world)] + [self.nx]
         self.timeout_s = collective_timeout_s()
         self.bytes_moved = 0
+        self.device = device
+
+    def _bounded(self, work, what):
+        """wait for an async collective: host-blocking backends against the deadline; "nccl" orders the stream (the
+        group's own timeout -- pg_timeout -- is the bound there, as for every RCCL wait of this module)"""
+        if work is None:
+            return
+        if self.dist.get_backend(self.group) == "nccl":
+            work.wait()
+            return
+        import datetime as _dt
+        try:
+            ok = work.wait(timeout=_dt.timedelta(seconds=self.timeout_s))
+        except RuntimeError as exc:
+            raise _lib.MfsTimeout(f"{what} failed with status {_lib.MFS_E_TIMEOUT}: wait timed out on rank "
+                                  f"{self.rank} [{type(exc).__name__}: {str(exc)[:160]}]") from None
+        if ok is False:
+            raise _lib.MfsTimeout(f"{what} failed with status {_lib.MFS_E_TIMEOUT}: wait timed out on rank {self.rank}")
+
+    def exchange_counts(self, counts, device=None):
+        """all-gather of a small int64 vector (one per rank) -> [W, len] host tensor; operands on the collective device"""
+        import torch
+        cd = coll_device(self.dist, self.group, device if device is not None else self.device)
+        mine = counts.to(device=cd, dtype=torch.int64).contiguous()
+        allc = [torch.zeros_like(mine) for _ in range(self.world)]
+        self._bounded(self.dist.all_gather(allc, mine, group=self.group, async_op=True), "band count exchange")
+        return torch.stack([c.cpu() for c in allc], dim=0)
+
+    def allreduce_scalar(self, value, op="max", device=None):
+        """one double combined over the ranks (the CFL maximum of the sharded time step); returns a float"""
+        import torch
+        cd = coll_device(self.dist, self.group, device if device is not None else self.device)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=cd)
+        rop = {"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN, "sum": self.dist.ReduceOp.SUM}[op]
+        self._bounded(self.dist.all_reduce(t, op=rop, group=self.group, async_op=True), "band scalar all-reduce")
+        return float(t.cpu().item())
 
     def cells(self, r=None):
         r = self.rank if r is None else r
@@ -525,15 +572,8 @@ class SlabBands:
         recvs = [((torch_empty_like_cpu(t) if staged else t), q, t) for t, q in ops_recv]
         ops = [dist.P2POp(dist.isend, t, q, self.group) for t, q in sends]
         ops += [dist.P2POp(dist.irecv, t, q, self.group) for t, q, _ in recvs]
-        import datetime as _dt
         for w in dist.batch_isend_irecv(ops):
-            try:
-                ok = w.wait(timeout=_dt.timedelta(seconds=self.timeout_s)) if dist.get_backend(self.group) != "nccl" else w.wait()
-            except RuntimeError as exc:
-                raise _lib.MfsTimeout(f"band exchange failed with status {_lib.MFS_E_TIMEOUT}: wait timed out on rank "
-                                      f"{self.rank} [{type(exc).__name__}: {str(exc)[:160]}]") from None
-            if ok is False:
-                raise _lib.MfsTimeout(f"band exchange failed with status {_lib.MFS_E_TIMEOUT}: wait timed out on rank {self.rank}")
+            self._bounded(w, "band exchange")
         if staged:
             for buf, _, dst in recvs:
                 dst.copy_(buf)
@@ -591,9 +631,9 @@ class SlabBands:
         if W == 1:
             return fields
         keep = dest == me
-        counts = torch.bincount(dest, minlength=W).to(torch.int64).cpu()
-        allc = [torch.zeros(W, dtype=torch.int64) for _ in range(W)]
-        dist.all_gather(allc, counts, group=self.group)             # allc[q][r] = particles q sends to r
+        counts = torch.bincount(dest, minlength=W).to(torch.int64)
+        allc = self.exchange_counts(counts, device=fields[0].device)   # allc[q][r] = particles q sends to r
+        counts = counts.cpu()
         widths = []
         for f in fields:
             w = 1

@@ -235,7 +235,7 @@ class ShardedNotebookSimulation(SlabNotebookSimulation):
     def __init__(self, *args, dist, group=None, transport="auto", **kw):
         super().__init__(*args, dist=dist, group=group, transport=transport, **kw)
         from mfs.dist import SlabBands
-        self.bands = SlabBands(dist, group, self.GRES[0])
+        self.bands = SlabBands(dist, group, self.GRES[0], device=self.device)
         p = self.particle
         p.id = torch.arange(p.num_particles, dtype=torch.int64, device=self.device)
         self.total_particles = p.num_particles
@@ -262,16 +262,17 @@ class ShardedNotebookSimulation(SlabNotebookSimulation):
 
     def gather_particles(self):
         """(id, x, v) of all particles, sorted by id, on every rank (inspection / tests: a whole-set collective)"""
+        from mfs.dist import coll_device
         p, dist = self.particle, self.dist
-        n = torch.tensor([p.num_particles], dtype=torch.int64)
-        ns = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
-        dist.all_gather(ns, n, group=self.group)
-        mine = torch.cat([p.id.to(torch.float64)[:, None], p.x, p.v], dim=1).cpu()
+        # operands on the group's collective device (an RCCL group has no CPU backend); the table comes back to the host
+        cd = coll_device(dist, self.group, self.device)
+        ns = self.bands.exchange_counts(torch.tensor([p.num_particles], dtype=torch.int64))[:, 0]
+        mine = torch.cat([p.id.to(torch.float64)[:, None], p.x, p.v], dim=1).to(cd)
         parts = []
         for r in range(self.world):
-            buf = mine if r == self.rank else torch.empty((int(ns[r]), 7), dtype=torch.float64)
+            buf = mine if r == self.rank else torch.empty((int(ns[r]), 7), dtype=torch.float64, device=cd)
             dist.broadcast(buf, src=r, group=self.group)
-            parts.append(buf)
+            parts.append(buf.cpu())
         allp = torch.cat(parts, dim=0)
         allp = allp[torch.argsort(allp[:, 0])]
         return allp[:, 0].to(torch.int64), allp[:, 1:4], allp[:, 4:7], [int(v) for v in ns]
@@ -297,9 +298,8 @@ class ShardedNotebookSimulation(SlabNotebookSimulation):
 
         t = time.perf_counter()
         vloc = torch.sqrt((p.v ** 2).sum(dim=-1)).max().item() if p.num_particles else 0.0
-        vm = torch.tensor([vloc], dtype=torch.float64)
-        dist.all_reduce(vm, op=dist.ReduceOp.MAX, group=self.group)
-        cfl_dt = self.GDX / max(1e-10, vm.item())
+        vmax = B.allreduce_scalar(vloc, "max")          # operand on the collective device: RCCL has no CPU backend
+        cfl_dt = self.GDX / max(1e-10, vmax)
         dt = min(self.DT, cfl_dt, duration_left)
         self.current_time += dt
         p.x += p.v * dt

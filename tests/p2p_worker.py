@@ -185,6 +185,27 @@ def timestep_synth_mode(rank, world, out, dev):
         sim.close()
 
 
+def rccl_world1_mode(rank, world, path, out, dtname, dev):
+    """every collective form of the sharded time step on an RCCL group.  World 1 (all one GPU admits),
+    so the exchanges that `world == 1` short-cuts are driven directly: the count all-gather, the scalar all-reduce, the
+    table broadcast of gather_particles, and a batched isend / irecv of DEVICE planes to this very rank (SlabBands._run's
+    non-staged branch).  Then two whole steps of ShardedNotebookSimulation, as tools/bench_timestep.py runs them."""
+    from mfs.dist import SlabBands
+    assert dist.get_backend() == "nccl" and world == 1
+    B = SlabBands(dist, None, 12, device=dev)
+    c = B.exchange_counts(torch.tensor([3, 4, 5], dtype=torch.int64, device=dev))
+    assert c.shape == (1, 3) and c.tolist() == [[3, 4, 5]] and not c.is_cuda
+    c = B.exchange_counts(torch.tensor([7], dtype=torch.int64))           # a host operand: moved to the device for the collective
+    assert c.tolist() == [[7]]
+    assert B.allreduce_scalar(2.5, "max") == 2.5 and B.allreduce_scalar(-1.0, "sum") == -1.0
+    src = torch.arange(2 * 5 * 3, dtype=torch.float64, device=dev).reshape(2, 5, 3)
+    dst = torch.zeros_like(src)
+    B._run([(src, 0)], [(dst, 0)])                                       # device planes through RCCL send / recv
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst) and B.bytes_moved == src.numel() * 8
+    timestep_sharded_mode(rank, world, path, out, dtname, dev)
+
+
 def _close_after_fault(win):
     """teardown of the fault-injection modes: the group may be broken by the timed-out collective (gloo closes the
     pair), so the window's closing barrier is best-effort and the process leaves without a collective teardown."""
@@ -203,7 +224,19 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     from mfs.dist import pg_timeout
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=pg_timeout())
+    if os.environ.get("P2P_TEST_BACKEND") == "nccl":
+        # a REAL RCCL group (one rank: RCCL refuses two ranks on one device) -- the launchers' backend on the GPUs
+        # (bench.py, tools/bench_timestep.py); every small host-side collective must then run on device operands
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev,
+                                timeout=pg_timeout())
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=pg_timeout())
+    if os.environ.get("P2P_TEST_MODE") == "rccl_world1":
+        try:
+            rccl_world1_mode(rank, world, path, out, dtname, dev)
+        finally:
+            dist.destroy_process_group()
+        return
     if os.environ.get("P2P_TEST_MODE") == "lost_peer_viscosity":
         # fault injection, viscosity window loop: rank 1 maps its window and never takes part in the solve
         from mfs import _lib

@@ -64,5 +64,8 @@ def test_c_viscosity_apply_and_cg_vs_golden(name):
     np.testing.assert_allclose(h[:n], hg[:n], rtol=1e-10)
     assert abs(res["iterations"] - int(g["iters"])) <= max(2, int(g["iters"]) // 10)
     xg = np.concatenate([g[k].ravel() for k in ("x_x", "x_y", "x_z")])
-    # converged field: 1e-4 of the field maximum, as everywhere (the history is rounding-chaotic past its leading window)
-    np.testing.assert_allclose(res["x"], xg, rtol=0, atol=1e-4 * np.abs(xg).max())
+    # converged field: 1e-4 of the field maximum, as everywhere (the history is rounding-chaotic past its leading window);
+    # the ill-conditioned mu = 50 scene: 1e-3 -- its converged field moves by 3.6e-4 of its maximum when only the rounding of
+    # this very oracle changes (tests/golden/envelope_v3d_c_16_mu50.npz: x_dev_max).  Round 2 asserted 1e-4 there and passed
+    # or failed with the number of OpenMP threads.
+    np.testing.assert_allclose(res["x"], xg, rtol=0, atol=(1e-3 if "mu50" in name else 1e-4) * np.abs(xg).max())

@@ -137,6 +137,24 @@ def test_two_full_steps_particles_sharded(world, tmp_path):
         assert (res[0]["counts2"] > 0).sum() >= 2, res[0]["counts2"]
 
 
+def test_sharded_step_on_an_rccl_group(tmp_path):
+    """the sharded time step as the multi-GPU launchers run it -- on an "nccl" (RCCL) group, which has no CPU backend:
+    the CFL all-reduce, the migration count exchange and gather_particles must move DEVICE operands (round 2 they were
+    host tensors and raised on the first step()).  One rank (RCCL admits one rank per device); the collectives that a
+    one-rank run short-cuts are driven directly in the worker (rccl_world1_mode), device planes travel through
+    batch_isend_irecv.  Results against the executed-reference goldens as in the gloo runs."""
+    from test_p2p_gpu import _run_ranks
+    g = golden("step_a_12x16x12")
+    res = _run_ranks("step_a_12x16x12", 1, tmp_path, "f64", P2P_TEST_MODE="rccl_world1", P2P_TEST_BACKEND="nccl")
+    r = res[0]
+    for s in range(int(g["steps"])):
+        move = np.abs(g[f"px{s + 1}"] - g["px0"]).max()
+        assert float(r[f"dt{s + 1}"]) == pytest.approx(float(g["dts"][s]), rel=1e-12)
+        assert int(r[f"counts{s + 1}"].sum()) == g["px0"].shape[0]
+        np.testing.assert_allclose(r[f"px{s + 1}"], g[f"px{s + 1}"], rtol=0, atol=1e-4 * move * (s + 1))
+        np.testing.assert_allclose(r[f"pv{s + 1}"], g[f"pv{s + 1}"], rtol=0, atol=2e-3 * np.abs(g[f"pv{s + 1}"]).max())
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_two_full_steps_particles_sharded_with_the_jacobi_option(world, tmp_path):
     """the sharded time step with all three solves Jacobi-preconditioned THROUGH THE WINDOW SLAB LOOPS (pressure, density:
