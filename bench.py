@@ -56,6 +56,10 @@ def parse():
                     help="1 GPU: run the peer-to-peer slab loop on a 1-rank window to price its launches")
     ap.add_argument("--b2b", action="store_true", help="also time back-to-back applies (cache-warm; not the CG number)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="CG iterations of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--repeat", type=int, default=0,
+                    help="timed blocks of exactly --steps iterations each (0 = auto: 9 when --steps < 100, else 1); ms_per_step is "
+                         "their median, min / max are reported beside it")
+    ap.add_argument("--no-side-legs", action="store_true", help="headline, roofline and parity only (skip config 2 / 3 / 4 / 5 legs)")
     return ap.parse_args()
 
 
@@ -259,33 +263,43 @@ def notebook_grid_leg(torch, dev):
             "us_per_iteration": round(dt / n * 1e6, 2), "iters_per_s": round(n / dt, 1), "parity_check": pc}
 
 
-def viscosity_leg(torch, dev, n, steps, with_parity):
-    """BASELINE config 3 (`ViscosityCGSolver3D`, buckling-like scene, fp32 state) at n^3: time per CG iteration of the native
-    loop, the operator apply (k_vcg_apply_march, csrc/mfs_vcg_march.h) bracketed by HIP events inside real iterations against
-    its algorithmic bytes (13 scalars + 1 packed mask byte per cell), and -- config 3's own size -- the
-    first 10 iterations against the oracle's C restatement of the viscosity CG."""
+def viscosity_leg(torch, dev, n, steps, with_parity, precision="fp32", ev_over=0.0):
+    """BASELINE config 3 (`ViscosityCGSolver3D`, buckling-like scene) on an n^3 grid (or the grid tuple `n`), state
+    `precision`: time per CG iteration of the native loop; the operator apply (k_vcg_apply_march, csrc/mfs_vcg_march.h)
+    bracketed by HIP events inside real iterations against its algorithmic bytes (13 scalars + 1 packed mask byte per cell,
+    DESIGN.md section 4) -- with the default compressed class access AND with dense access; the census of the classes; and
+    the first 10 iterations against the oracle's C restatement of the viscosity CG."""
     import numpy as np
     from mfs import scenes
     import solver.ViscosityCGSolver3D as V
-    gres = (n, n, n)
+    gres = (n, n, n) if isinstance(n, int) else tuple(n)
+    esz = 4 if precision == "fp32" else 8
     sc = scenes.viscosity_scene_3d(gres, seed=3, device=dev)
-    s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision="fp32", device=dev)
+    s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision=precision, device=dev)
     scale, mu = sc["dt"] / s.cell_vol / sc["rho"], sc["mu"]
     torch.div(sc["lvol"], s.cell_vol * 0.125, out=s.vol)
-    s.x_x.copy_(sc["vx"]); s.x_y.copy_(sc["vy"]); s.x_z.copy_(sc["vz"])
-    V.extrapolate(gres, 3, s.x_x, s.x_y, s.x_z, sc["sphi"])
+
+    def start():
+        s.x_x.copy_(sc["vx"]); s.x_y.copy_(sc["vy"]); s.x_z.copy_(sc["vz"])
+        V.extrapolate(gres, 3, s.x_x, s.x_y, s.x_z, sc["sphi"])
+    start()
     V.initialize_solver(gres, scale, mu, s.x_x, s.x_y, s.x_z, sc["sphi"], sc["sv"], s.vol, s.b_x, s.b_y, s.b_z)
     e, f = s._engine, s._flat
     e.setup(scale, mu, sc["sphi"], s.vol)
     e.bind(f["b"], f["x"], f["d"], f["r"], f["q"])
     host = lambda t: t.double().cpu().numpy()  # noqa: E731
-    out = {"workload": f"ViscosityCGSolver3D {n}^3 buckling-like scene, fp32 state", "apply_kernel": e.apply_kernel(),
-           "loop": "fused" if e.loop_info()["fused"] else "three launches (march | r update | direction + x update)"}
+    info = e.loop_info()
+    out = {"workload": "ViscosityCGSolver3D %s buckling-like scene, %s state" % ("x".join(map(str, gres)), precision),
+           "apply_kernel": e.apply_kernel(),
+           "loop": ("resident: one launch per batch (csrc/mfs_vcg_resident.h)" if info.get("resident") else
+                    "fused" if info["fused"] else
+                    "two launches (march | merged vector phases)" if info["merged_vector_phases"] else
+                    "three launches (march | r update | direction + x update)")}
     if with_parity:
         from oracle import cbaseline
-        iters, tol = 10, 1e-5
+        iters, tol = 10, (1e-5 if precision == "fp32" else 1e-9)
         x0, b = host(f["x"]), host(f["b"])
-        vol = s.vol.float().double().cpu().numpy()          # fp32 state stores the class samples in fp32: same values
+        vol = s.vol.to(f["x"].dtype).double().cpu().numpy()          # the state precision's class samples: same values
         e.begin(0.0)
         e.iterate(iters)
         e.finish()
@@ -297,10 +311,10 @@ def viscosity_leg(torch, dev, n, steps, with_parity):
         ok = bool(len(h) == len(ref["history"]) == 2 * iters + 1 and dev_h < tol and dev_x < tol)
         out["parity_check"] = {"iterations": iters, "history_max_rel_dev": dev_h, "x_max_dev_rel_to_max": dev_x,
                                "tolerance": tol, "ok": ok, "oracle": "oracle/mfs_oracle_c.c (viscosity operator + CG loop, fp64)"}
+        del ref, x0, b, vol
         if not ok:
             raise AssertionError(f"bench viscosity parity self-check failed: {out}")
-        s.x_x.copy_(sc["vx"]); s.x_y.copy_(sc["vy"]); s.x_z.copy_(sc["vz"])
-        V.extrapolate(gres, 3, s.x_x, s.x_y, s.x_z, sc["sphi"])
+        start()
     e.begin(0.0)
     e.iterate(10)
     torch.cuda.synchronize()
@@ -310,37 +324,200 @@ def viscosity_leg(torch, dev, n, steps, with_parity):
     dt = time.perf_counter() - t0
     st = e.poll()
     assert st["iterations"] == 10 + steps and st["delta"] == st["delta"], st
-    # the apply launch inside real iterations (phase form of the same kernels: the events bracket one launch each)
-    reps = 24
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b_ in ev:
-        a.record()
-        e.phase_apply()
-        b_.record()
-        e.phase_reduce(0)
-        e.phase_update_xr()
-        e.phase_reduce(1)
-        e.phase_update_d()
-    torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b_) for a, b_ in ev) / reps
-    # ... and back to back (what tools/vapply_time.py and profiles/r02_visc_* quote)
-    a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e.phase_apply()
-    a.record()
-    for _ in range(reps):
-        e.phase_apply()
-    b_.record()
-    torch.cuda.synchronize()
-    ms_b2b = a.elapsed_time(b_) / reps
-    cells = n ** 3
-    ab = cells * (13 * 4 + 1)
-    out.update({"us_per_iteration": round(dt / steps * 1e6, 2), "Mcells_per_s": round(cells * steps / dt / 1e6, 1),
-                "apply": {"kernel": "k_vcg_apply_march<float, 4> (q = A d, three coupled components, d.q partials)",
-                          "algorithmic_bytes": ab, "kernel_ms": round(ms, 5), "achieved": round(ab / (ms * 1e-3) / 1e9, 1),
-                          "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s",
-                          "kernel_ms_back_to_back": round(ms_b2b, 5),
-                          "frac_back_to_back": round(ab / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}})
+    cells = gres[0] * gres[1] * gres[2]
+    out.update({"us_per_iteration": round(dt / steps * 1e6, 2), "Mcells_per_s": round(cells * steps / dt / 1e6, 1)})
+    if e.apply_kernel() == "march":
+        out["class_census"] = e.class_census()
+    if cells >= 64 ** 3:
+        # the apply launch inside real iterations (phase form of the same kernels: the events bracket one launch each)
+        reps = 24
+        ab = cells * (13 * esz + 1)
+
+        def bracketed():
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b_ in ev:
+                a.record()
+                e.phase_apply()
+                b_.record()
+                e.phase_reduce(0)
+                e.phase_update_xr()
+                e.phase_reduce(1)
+                e.phase_update_d()
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b_) for a, b_ in ev)
+            return ts[len(ts) // 2]
+
+        def back_to_back():
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e.phase_apply()
+            a.record()
+            for _ in range(reps):
+                e.phase_apply()
+            b_.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b_) / reps
+
+        def figures(label):
+            ms, ms_b2b = bracketed(), back_to_back()
+            return {"kernel": label, "algorithmic_bytes": ab, "kernel_ms": round(ms, 5), "kernel_ms_is": "median of %d bracketed launches" % reps,
+                    "kernel_ms_minus_event_pair": round(ms - ev_over, 5),
+                    "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s",
+                    "kernel_ms_back_to_back": round(ms_b2b, 5),
+                    "frac_back_to_back": round(ab / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        tname = "float, 4" if precision == "fp32" else "double, 2"
+        out["apply"] = figures("k_vcg_apply_march<%s, ..., COMP=true> (q = A d, three coupled components, d.q partials; class arrays "
+                               "read only for z-vectors that are neither all air nor all bulk liquid)" % tname)
+        out["apply"]["frac_is"] = ("EFFECTIVE rate on this scene (algorithmic bytes / kernel time / peak): with compressed class access "
+                                   "the kernel moves fewer bytes than the algorithmic count; `apply_dense` is the scene-independent figure")
+        e.set_compress(False)
+        out["apply_dense"] = figures("k_vcg_apply_march<%s, ..., COMP=false> (every class array read in full)" % tname)
+        e.set_compress(True)
     del s, e, f, sc
+    torch.cuda.empty_cache()
+    return out
+
+
+def config4_rank_share_leg(args, torch, dev, seed, ev_over=0.0):
+    """One rank's share of BASELINE config 4 (`PressureCGSolver3D` 512^3 on 8 GPUs): the slab of rank 3 of 8 -- 64 owned
+    planes + 2 ghost planes of 512 x 512, fp32 state -- through the WINDOW slab loop on a 1-rank window (the launches, the
+    edge / interior split and the in-launch all-reduce of the multi-GPU path, no peer).  This is the per-rank cost the
+    >= 6x claim rests on; the first 10 iterations are checked against the C oracle on the same slab."""
+    import numpy as np
+    import torch.distributed as dist
+    from mfs import dist as mdist
+    from mfs.p2p import P2PWindow
+    from mfs.pcg import PcgEngine
+    from oracle import cbaseline
+    tdt = torch.float32
+    ggrid = GRIDS[8]
+    lo, hi = mdist.SlabPartition(ggrid[0], 8, 3).local_range
+    lgres = (hi - lo, ggrid[1], ggrid[2])
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=mdist.pg_timeout())
+    out = {"workload": f"PressureCGSolver3D slab {lgres[0]}x{lgres[1]}x{lgres[2]} (planes {lo}..{hi} of the 512^3 pool scene: rank 3 of 8), fp32 state"}
+    win = None
+    try:
+        wx, wy, wz, lphi, (b, x, d, r, q) = build_problem(torch, dev, tdt, lgres, ggrid, seed, (lo, hi))
+        eng = PcgEngine(lgres, tdt, dev)
+        eng.setup(lphi, wx, wy, wz)
+        eng.bind(b, x, d, r, q)
+        part = mdist.SlabPartition(lgres[0], 1, 0)
+        win = P2PWindow(dist, lgres[1] * lgres[2] * 4, dev)
+        out["p2p_selftest"] = "ok" if win.ok else win.why
+        cg = mdist.SlabCG(eng, part, d, dist, force_multi=True, window=win if win.ok else None)
+        # parity first: 10 iterations through this very loop against the C oracle
+        iters = 10
+        cg.begin(0.0)
+        cg.iterate(iters)
+        cg.finish()
+        torch.cuda.synchronize()
+        out["transport"] = cg.mode
+        h = eng.history()[: 2 * iters + 1]
+        host = lambda t: t.double().cpu().numpy()  # noqa: E731
+        ref = cbaseline.cg(lgres, host(b), host(lphi), host(wx), host(wy), host(wz), 0.0, iters, 2 * iters + 1)
+        dev_h = float(np.max(np.abs(h - ref["history"]) / np.abs(ref["history"])))
+        dev_x = float(np.max(np.abs(host(x) - ref["x"])) / np.max(np.abs(ref["x"])))
+        ok = bool(len(h) == 2 * iters + 1 and dev_h < 1e-5 and dev_x < 1e-4)
+        out["parity_check"] = {"iterations": iters, "history_max_rel_dev": dev_h, "x_max_dev_rel_to_max": dev_x, "tolerance": 1e-5,
+                               "x_tolerance": 1e-4, "ok": ok, "oracle": "oracle/mfs_oracle_c.c on the same slab (ghost planes as boundary planes)"}
+        del ref
+        if not ok:
+            raise AssertionError(f"config4_rank_share parity self-check failed: {out}")
+        n = max(50, min(args.steps, 200))
+        cg.begin(0.0)
+        cg.iterate(10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cg.iterate(n)
+        t_enq = time.perf_counter() - t0
+        cg.finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cells = (lgres[0] - 2) * lgres[1] * lgres[2]           # owned planes
+        out.update({"us_per_iteration": round(dt / n * 1e6, 2), "host_enqueue_us_per_iteration": round(t_enq / n * 1e6, 2),
+                    "owned_Mcells_per_s": round(cells * n / dt / 1e6, 1), "iterations_timed": n,
+                    "eight_ranks_at_this_rate_Mcells_per_s": round(8 * cells * n / dt / 1e6, 1),
+                    "note": "1-rank window: every launch, the edge / interior split and the in-launch reductions of the multi-GPU "
+                            "loop, no xGMI traffic -- an upper bound on what 8 ranks can reach, not a measurement of them"})
+        del eng, cg, wx, wy, wz, lphi, b, x, d, r, q
+    finally:
+        if win is not None:
+            win.close()
+        if own:
+            dist.destroy_process_group()
+        torch.cuda.empty_cache()
+    return out
+
+
+def timestep_leg(torch, dev, N=128, steps=3):
+    """BASELINE config 5's pipeline on ONE GPU at N^3 (tools/bench_timestep.py's scene: flipped container, four slanted plates,
+    a fluid block of (N/2)^3 cells at 8 particles per cell, mu = 1, fp64 state): per-stage wall clock of whole time steps --
+    and the pressure solve of the LAST step, inputs captured as it ran, first 10 iterations against the C oracle."""
+    import numpy as np
+    import notebook_sim as NSIM
+    import solver.sdf3D as sdf
+    import solver.PressureCGSolver3D as P
+    from mfs.pcg import PcgEngine
+    from oracle import cbaseline
+    gdx = 1.0 / N
+    rb_d, rb_map = sdf.generate_rb(None, {}, 'cube', ['box', 1 - 4 * gdx, 1 - 4 * gdx, 1 - 4 * gdx], flip=True, center=[0, 0.5, 0], device=dev)
+    h = 0.35
+    for nm, par, c, ax, ang in (("p1", ['box', 0.67, 0.05, 1.2], [-0.42, h, 0], [0, 0, 1], -45), ("p2", ['box', 0.67, 0.05, 1.2], [0.42, h, 0], [0, 0, 1], 45),
+                                ("p3", ['box', 1.2, 0.05, 0.67], [0, h, -0.42], [1, 0, 0], 45), ("p4", ['box', 1.2, 0.05, 0.67], [0, h, 0.42], [1, 0, 0], -45)):
+        rb_d, rb_map = sdf.generate_rb(rb_d, rb_map, nm, par, flip=False, center=c, axis=ax, angle=ang)
+    px = NSIM.add_box([0.0, 0.7, 0.0], [0.5, 0.5, 0.5], gdx / 2, np.random.default_rng(0))
+    sim = NSIM.NotebookSimulation((N, N, N), gdx, [-0.5, 0.0, -0.5], rb_d, px, gdx / 2, mu=1.0, device=dev)
+    sim.particle.v[:, 0] = -2.0
+    sim.step()                                   # warm-up step (allocations, first launches)
+    cap = {}
+    solve0 = sim.PressureSolver.solve
+
+    def spy(vx, vy, vz, sphi, sv, lphi, wx=None, wy=None, wz=None, **kw):
+        cap.update(vx=vx.clone(), vy=vy.clone(), vz=vz.clone(), sphi=sphi, sv=sv, lphi=lphi.clone(), wx=wx.clone(), wy=wy.clone(), wz=wz.clone())
+        return solve0(vx, vy, vz, sphi, sv, lphi, wx=wx, wy=wy, wz=wz, **kw)
+    tim, its = {}, []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if k == steps - 1:
+            sim.PressureSolver.solve = spy
+        sim.step(timings=tim)
+        its.append((sim.DensitySolver.iterations, sim.ViscositySolver.iterations, sim.PressureSolver.iterations))
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    out = {"workload": f"notebook time step {N}^3, {sim.particle.num_particles} particles, mu=1, fp64 state, 1 GPU", "steps": steps,
+           "s_per_step": round(t_all / steps, 4), "stage_ms_per_step": {k: round(v / steps * 1e3, 2) for k, v in tim.items()},
+           "cg_iterations(density,viscosity,pressure)": its}
+    # the captured pressure solve against the C oracle
+    g = (N, N, N)
+    tdt = torch.float64
+    b, x, d, r, q = (torch.zeros(g, dtype=tdt, device=dev) for _ in range(5))
+    P.initialize_solver(sim.PressureSolver.cell_size, g, cap["vx"], cap["vy"], cap["vz"], cap["sphi"], cap["sv"], cap["lphi"], b, cap["wx"], cap["wy"], cap["wz"])
+    eng = PcgEngine(g, tdt, dev)
+    eng.setup(cap["lphi"], cap["wx"], cap["wy"], cap["wz"])
+    eng.bind(b, x, d, r, q)
+    iters = 10
+    eng.begin(0.0)
+    eng.iterate(iters)
+    eng.finish()
+    torch.cuda.synchronize()
+    hh = eng.history()[: 2 * iters + 1]
+    host = lambda t: t.double().cpu().numpy()  # noqa: E731
+    ref = cbaseline.cg(g, host(b), host(cap["lphi"]), host(cap["wx"]), host(cap["wy"]), host(cap["wz"]), 0.0, iters, 2 * iters + 1)
+    dev_h = float(np.max(np.abs(hh - ref["history"]) / np.abs(ref["history"])))
+    dev_x = float(np.max(np.abs(host(x) - ref["x"])) / np.max(np.abs(ref["x"])))
+    ok = bool(len(hh) == 2 * iters + 1 and dev_h < 1e-9 and dev_x < 1e-9)
+    out["parity_check"] = {"what": "the pressure solve of the last timed step (inputs captured as it ran: post-viscosity velocities, the "
+                                   "density solve's face weights), default engine, first 10 CG iterations", "iterations": iters,
+                           "history_max_rel_dev": dev_h, "x_max_dev_rel_to_max": dev_x, "tolerance": 1e-9, "ok": ok,
+                           "oracle": "oracle/mfs_oracle_c.c"}
+    if not ok:
+        raise AssertionError(f"timestep parity self-check failed: {out}")
+    sim.PressureSolver.solve = solve0
+    del sim, eng, cap, b, x, d, r, q
     torch.cuda.empty_cache()
     return out
 
@@ -579,23 +756,38 @@ def main():
             elif ok:
                 cg, transport = cg_p2p, "p2p"
 
-    cg.begin(0.0)                          # tol = 0: never "converged", every step does full work
-    cg.iterate(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    cg.iterate(args.steps)
-    t_enq = time.perf_counter() - t0      # host time to enqueue the steps (no sync inside)
-    if transport in ("single", "p2p"):
-        eng.finish()                      # the one solution update the fused loop still owes (inside the timed region)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    st = eng.poll()
-    assert st["iterations"] == args.warmup + args.steps, st
-    assert st["delta"] == st["delta"], "NaN residual"
+    def timed_block(warm):
+        """W untimed warm-up steps, then EXACTLY args.steps steps bracketed by barrier + synchronize; max over the ranks"""
+        cg.begin(0.0)                      # tol = 0: never "converged", every step does full work
+        cg.iterate(warm)
+        sync()
+        t0_ = time.perf_counter()
+        cg.iterate(args.steps)
+        t_enq_ = time.perf_counter() - t0_   # host time to enqueue the steps (no sync inside)
+        if transport in ("single", "p2p"):
+            eng.finish()                   # the one solution update the fused loop still owes (inside the timed region)
+        sync()
+        dt_ = time.perf_counter() - t0_
+        if world > 1:
+            tt_ = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            dt_ = tt_.item()
+        st_ = eng.poll()
+        assert st_["iterations"] == warm + args.steps, st_
+        assert st_["delta"] == st_["delta"], "NaN residual"
+        return dt_, t_enq_
+
+    # A short run (the driver's --steps 20 is a 2.6 ms region) is repeated: 9 blocks of exactly --steps steps each, the
+    # MEDIAN is the reported time, min / max beside it (`steps` stays what was asked for)
+    n_blocks = args.repeat if args.repeat > 0 else (9 if args.steps < 100 else 1)
+    blocks = [timed_block(args.warmup) for _ in range(n_blocks)]
+    dts = sorted(b_[0] for b_ in blocks)
+    dt = dts[len(dts) // 2]
+    t_enq = sorted(b_[1] for b_ in blocks)[len(blocks) // 2]
+    block_info = {"blocks": n_blocks, "steps_per_block": args.steps, "ms_per_step_median": round(dt / args.steps * 1e3, 5),
+                  "ms_per_step_min": round(dts[0] / args.steps * 1e3, 5), "ms_per_step_max": round(dts[-1] / args.steps * 1e3, 5),
+                  "ms_per_step_first_block": round(blocks[0][0] / args.steps * 1e3, 5),
+                  "reported": "median" if n_blocks > 1 else "the one block"}
 
     # the other transport on the same problem, outside the timed region (diagnostic only)
     if world > 1 and transport == "p2p":
@@ -621,12 +813,24 @@ def main():
     visc_line = None
     jac_line = None
     cfg2_line = None
+    cfg4_line = None
+    ts_line = None
+    ev_over = 0.0
     if rank == 0 and not args.timed_loop_only:
         Nx, Ny, Nz = lgres
         cells_l = Nx * Ny * Nz
         reps = max(20, min(args.steps, 200))
         reps_leg = 32          # the side legs stay short: they share kernel templates with the timed loop (rocprof averages)
 
+        cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for s_ev, e_ev in cal:
+            s_ev.record()
+            e_ev.record()
+        torch.cuda.synchronize()
+        ev_over = sorted(a.elapsed_time(b_) for a, b_ in cal)[len(cal) // 2]
+        # NOT subtracted: an empty pair (~9 us) over-states what two records cost around a running kernel
+        # (rocprofv3 gives 63.2 us for the kernel whose bracketed time is 66.5 us); the bracketed time is the
+        # conservative figure and is what `achieved` uses.
         def time_apply(engine, n, robust=False):
             """average duration of the stencil launch inside real CG iterations: HIP events (on the stream the kernel is
             launched on) bracket each apply launch of n native iterations"""
@@ -657,6 +861,7 @@ def main():
             ms = time_apply(engine, reps_leg, robust=True)
             ab = alg_bytes_of(form, fused)
             return {"kernel": label, "algorithmic_bytes": ab, "kernel_ms": round(ms, 5), "kernel_ms_is": "median of %d launches" % reps_leg,
+                    "kernel_ms_minus_event_pair": round(ms - ev_over, 5),
                     "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
         form = eng.loop_info()
@@ -664,15 +869,6 @@ def main():
         if transport != "single":          # leave the slab loops' state behind: plain single-domain iterations
             eng.begin(0.0)
             eng.iterate(2)
-        cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
-        for s_ev, e_ev in cal:
-            s_ev.record()
-            e_ev.record()
-        torch.cuda.synchronize()
-        ev_over = sorted(a.elapsed_time(b_) for a, b_ in cal)[len(cal) // 2]
-        # NOT subtracted: an empty pair (~9 us) over-states what two records cost around a running kernel
-        # (rocprofv3 gives 63.2 us for the kernel whose bracketed time is 66.5 us); the bracketed time is the
-        # conservative figure and is what `achieved` uses.
         ms_cg = time_apply(eng, reps)
         ms_b2b = None
         if args.b2b:   # back-to-back applies (Infinity-Cache-warm; NOT what the CG loop sees)
@@ -696,7 +892,7 @@ def main():
         # measurement of this run; valid for the default workload only.  traffic_frac = those bytes / this run's kernel
         # time / peak: the fraction of the HBM roofline the kernel's real traffic amounts to.
         traffic, traffic_src, dense_traffic = None, None, None
-        for name in ("r02_pmc_apply.json", "r01_pmc_apply.json"):
+        for name in ("r03_pmc_apply.json", "r02_pmc_apply.json", "r01_pmc_apply.json"):
             pj = os.path.join(REPO, "profiles", name)
             if os.path.exists(pj) and transport == "single":
                 try:
@@ -719,7 +915,11 @@ def main():
               "traffic_frac": (round(traffic / (ms_cg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
               "traffic_source": traffic_src,
               "algorithmic_bytes": alg_bytes, "kernel_ms": round(ms_cg, 5),
-              "event_pair_overhead_ms": round(ev_over, 5)}
+              "kernel_ms_minus_event_pair": round(ms_cg - ev_over, 5),
+              "event_pair_overhead_ms": round(ev_over, 5),
+              "event_pair_note": "an empty record pair; NOT subtracted in `achieved` / `frac` (it over-states what two records cost "
+                                 "around a running kernel): kernel_ms_minus_event_pair is the lower bracket, rocprofv3's kernel-only "
+                                 "average (profiles/) lies between the two"}
         # the PLAIN stencil apply (6N^3 + 3N^2 scalars -- the figure BASELINE.md's 60 % target is
         # stated on), inside the three-kernel form of the loop (direction update unfused)
         rf["plain_stencil_apply"] = leg(eng, False, "k_pcg_apply_march<..., FUSE=false> (6N^3+3N^2 scalars, SURVEY.md 8(d)), "
@@ -772,11 +972,18 @@ def main():
                     print(f"bench side leg {fn.__name__} failed: {exc!r}", file=sys.stderr, flush=True)
                     torch.cuda.empty_cache()
                     return {"error": repr(exc)[:400]}
-            cfg2_line = soft(config2_leg, args, torch, dev, seed)
-            visc_line = {"config3_128": soft(viscosity_leg, torch, dev, 128, 200, True),
-                         "n256": soft(viscosity_leg, torch, dev, 256, 60, False)}
-            jac_line = soft(jacobi_leg, args, torch, dev, tdt, lgres, seed)
-            jac_line["viscosity"] = soft(viscosity_jacobi_leg, torch, dev, 128)
+            if not args.no_side_legs:
+                cfg2_line = soft(config2_leg, args, torch, dev, seed)
+                visc_line = {"config3_128": soft(viscosity_leg, torch, dev, 128, 200, True, "fp32", ev_over),
+                             "n256": soft(viscosity_leg, torch, dev, 256, 60, False, "fp32", ev_over),
+                             # the drop-in's DEFAULT precision at the size beyond the Infinity Cache, with its own oracle check
+                             "f64_state": soft(viscosity_leg, torch, dev, 256, 40, True, "fp64", ev_over),
+                             # the reference's OWN grid (3D_viscous_fluid_sim.ipynb:651-656): the resident small-grid loop
+                             "notebook_grid": soft(viscosity_leg, torch, dev, (48, 80, 48), 2000, True, "fp64", ev_over)}
+                jac_line = soft(jacobi_leg, args, torch, dev, tdt, lgres, seed)
+                jac_line["viscosity"] = soft(viscosity_jacobi_leg, torch, dev, 128)
+                cfg4_line = soft(config4_rank_share_leg, args, torch, dev, seed, ev_over)
+                ts_line = soft(timestep_leg, torch, dev, 128, 3)
     if world > 1:
         dist.barrier()
 
@@ -800,13 +1007,17 @@ def main():
                        "transport": transport,
                        "step": "one CG iteration (apply + 2 dots + x/r/d updates)"},
             "iters_per_s": round(args.steps / dt, 2),
+            "timed_blocks": block_info,
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 5),
             "cg_iteration_hbm_gbs": round(iter_bytes / (dt / args.steps) / 1e9, 1),
             "roofline": rf,
             "residual_parity": ("checked over a window: CG on this operator is chaotic in rounding (the oracle departs from "
                                 "its own history by > 1e-2 after ~30 iterations when only its summation order changes, "
                                 "tests/test_oracle_sensitivity.py), so north_star's 1e-5 rel residual match is asserted on "
-                                "the first 10 iterations at the bench size (parity_check) and 8-10 on the goldens"),
+                                "the first 10 iterations at the bench size (parity_check) and 8-10 on the goldens; over the WHOLE "
+                                "history the HIP solvers stay inside the rounding envelope of the oracle itself -- dev_k <= 4 E_k + 1e-9 "
+                                "for every entry k, E_k from 80 rounding variants of the C oracle (tests/test_history_envelope.py, "
+                                "tests/golden/envelope_*.npz)"),
         }
         if parity is not None:
             out["parity_check"] = parity
@@ -820,6 +1031,10 @@ def main():
             out["viscosity"] = visc_line
         if jac_line is not None:
             out["jacobi_preconditioned"] = jac_line
+        if cfg4_line is not None:
+            out["config4_rank_share"] = cfg4_line
+        if ts_line is not None:
+            out["timestep_128"] = ts_line
         if shared:
             out["rehearsal"] = "all ranks share cuda:0 over gloo (MFS_BENCH_SHARED_GPU=1): code-path check, not a measurement"
         if tinfo:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MFS_ABI_VERSION 1
+#define MFS_ABI_VERSION 3   /* = the round the entry-point set last grew in */
 
 typedef enum { MFS_F32 = 0, MFS_F64 = 1 } mfs_dtype;
 
@@ -324,6 +324,14 @@ int mfs_vcg3d_finish(mfs_vcg3d* h, mfs_stream stream);
 /* 1 / 0: fused direction + x update in mfs_vcg3d_iterate / solve (default 0 -- measured slower, DESIGN.md section 4;
  * env MFS_VISC_FUSE); results bit-identical */
 int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on);
+/* compressed class access of the x-marching kernel (default on; env MFS_VISC_COMPRESS): per z-vector and plane a class
+ * (built by mfs_vcg3d_setup, stored in spare bits of the packed mask bytes) says whether every volume sample the
+ * vector's step loads is 0 (air), 1 (bulk liquid) or anything else; only the last kind reads the seven class arrays
+ * (lvol de-interleaved, ViscosityCGSolver3D.py:248-456 reads it at 7 of 8 doubled-grid parities).  Bit-identical. */
+int mfs_vcg3d_set_compress(mfs_vcg3d* h, int on);
+/* census of those classes after mfs_vcg3d_setup: counts_host[0] = z-vectors whose samples are all 0, [1] = all 1,
+ * [2] = the rest (the only ones that read the class arrays).  Diagnostic, host-synchronous. */
+int mfs_vcg3d_class_census(mfs_vcg3d* h, int64_t counts_host[3], mfs_stream stream);
 /* bit 0: mfs_vcg3d_iterate will run the fused 2-launch loop for the engine as bound and set up; bit 1: the small-problem
  * loop -- the r update (:592-601), the r.r reduction, the test / bookkeeping (:604-608) and the x / direction updates
  * (:595-597, :609-610) in ONE launch whose resident workgroups exchange their partial sums (csrc/mfs_cg_core.h
@@ -339,6 +347,14 @@ int mfs_vcg3d_set_jacobi(mfs_vcg3d* h, int on);
 /* 1 / 0: allow that small-problem loop (default 1; env MFS_RDX).  A launch that is not fully resident (shared GPU) times
  * out without having written anything; the next poll switches the engine to the three-launch loop for good. */
 int mfs_vcg3d_set_merged(mfs_vcg3d* h, int on);
+/* 1 / 0: allow the RESIDENT small-grid loop (default on where the grid qualifies; env MFS_VISC_RESIDENT): the loop
+ * ViscosityCGSolver3D.py:588-610 as ONE launch per mfs_vcg3d_iterate batch -- x, r, d, q of every face in the registers of
+ * up to 128 resident workgroups, d with its halo in LDS, dot products and halo faces exchanged as self-validating records
+ * (csrc/mfs_vcg_resident.h).  Same arithmetic per element; the dot products group differently, so histories agree with the
+ * launch-per-phase loop to rounding.  A launch that is not fully resident (shared GPU) times out at its first dot product
+ * without having written anything; the next poll switches the engine to the launch-per-phase loop for good.
+ * Bit 3 of mfs_vcg3d_loop_info. */
+int mfs_vcg3d_set_resident(mfs_vcg3d* h, int on);
 int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters_host, int* done_host,
                    double* delta_host, double* alpha_host, double* beta_host);
 int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_every,
@@ -464,6 +480,27 @@ int mfs_p2g_scatter3d(const int64_t gres[3], const double bound_min[3], const do
                       const double grid_bias[3], int axis, const void* px, int px_dt, const void* pm, int pm_dt,
                       const void* pv, int pv_dt, const void* pca, int pca_dt, int64_t num_particles,
                       void* gm, void* gv, int g_dt, mfs_stream stream);
+/* Tile-sorted forms of the three scatters (the build's own; same results up to the order of the fp atomics, which the
+ * reference leaves unspecified too).  mfs_particle_tile_sort3d buckets the particles by the tile of 8^3 CELLS their cell
+ * (floor((x - bound_min) / cell_size), clamped to gres) lies in: perm[num_particles] = particle indices tile by tile,
+ * tile_start[mfs_particle_tiles3d(gres) + 1] = segment starts; work = 2 * tiles + num_particles int32 of scratch.  The
+ * *_tiled entry points take that order and run one workgroup per tile with the tile's nodes in LDS (csrc/mfs_particles.hip);
+ * they stay correct when particles have moved since the sort (contributions outside the staged nodes take the global
+ * atomic), only slower.  p2g_particle / compute_fls_kernel / compute_fluid_volume_kernel: ipynb code cells 2, 4, 6. */
+int64_t mfs_particle_tiles3d(const int64_t gres[3]);
+int mfs_particle_tile_sort3d(const int64_t gres[3], const double bound_min[3], const double cell_size[3], const void* px,
+                             int px_dt, int64_t num_particles, int32_t* perm, int32_t* tile_start, int32_t* work,
+                             mfs_stream stream);
+int mfs_p2g_scatter3d_tiled(const int64_t gres[3], const double bound_min[3], const double cell_size[3],
+                            const double grid_bias[3], int axis, const void* px, int px_dt, const void* pm, int pm_dt,
+                            const void* pv, int pv_dt, const void* pca, int pca_dt, int64_t num_particles,
+                            const int32_t* perm, const int32_t* tile_start, void* gm, void* gv, int g_dt, mfs_stream stream);
+int mfs_fluid_levelset3d_tiled(const int64_t gres[3], const double bound_min[3], const double cell_size[3], double radius,
+                               const void* px, int px_dt, int64_t num_particles, const int32_t* perm,
+                               const int32_t* tile_start, void* phi, int phi_dt, mfs_stream stream);
+int mfs_fluid_volume3d_tiled(const int64_t vres[3], const double bound_min[3], const double cell_size[3], const void* px,
+                             int px_dt, double pvol, int64_t num_particles, const int32_t* perm, const int32_t* tile_start,
+                             void* gvol, int g_dt, mfs_stream stream);
 /* replaces p2g_grid -- code cell 2: gv /= gm wherever gm > 0 (count = elements of the face array) */
 int mfs_p2g_normalize3d(int64_t count, const void* gm, void* gv, int g_dt, mfs_stream stream);
 /* replaces g2p_particle -- code cell 3: pv[:, axis] and the affine row pca[:, :] from the face array gv */

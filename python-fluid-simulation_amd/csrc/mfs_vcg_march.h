@@ -343,7 +343,16 @@ struct VmFuse {
 // RING: plane slots of the LDS ring.  4: planes x-1, x, x+1 are read while x+2 is written -- ONE barrier per plane.  3 (rows so
 // long that four slots of a 512-vector tile exceed the CU's LDS: fp64 380 < Nz <= 512, fp32 760 < Nz <= 1024): plane x+2 takes the
 // slot of plane x-1, after a second barrier.
-template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock, int RING = kVmRing>
+// COMP (compressed class access, round 3): bits 4-5 of the mask byte of a vector's FIRST cell (k_vcg_classify, once per
+// set-up) say whether every class sample this vector's step LOADS -- the seven classes at the vector itself, C at x-1 and
+// y-1, EXY at x+1 and y+1, EXZ at x+1, EYZ at y+1 -- is +0.0 (kVmClsZero: outside the liquid), 1.0 (kVmClsOne: inside it)
+// or anything else (0: MIXED).  Only MIXED vectors read the class arrays; the others take the constant, so their registers
+// hold exactly the values a load would have returned and everything downstream -- the rows, the DPP z-neighbours taken from
+// the neighbouring lanes' registers, the samples carried across steps -- is bit-identical to dense access.  In a liquid
+// solve most of the domain is air or bulk liquid: 7 of the kernel's 13 scalars per cell are then not moved at all.  The
+// class travels with the mask byte, requested two steps ahead so that it is known when the next step's loads are issued.
+constexpr unsigned kVmClsZero = 1, kVmClsOne = 2;
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock, int RING = kVmRing, bool COMP = false>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ ox, T* __restrict__ oy, T* __restrict__ oz,
                   int gmain, Box3 b0, Box3 b1, Box3 b2, int g0, int g1, double* __restrict__ partial,
@@ -351,6 +360,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   // the flag is REQUESTED here and tested where the first march's own loads have been issued: on a small grid the
   // launch is a chain of memory round trips, and flag -> planes was two of them (loads past a raised flag are harmless)
   const double dn = done_flag ? *done_flag : 0.0;
+  const T bulk = COMP ? *(const T*)c.bulk : (T)0;           // the constant of class kVmClsOne (k_vcg_classify compared against it)
   const double f_alpha = FUSE ? fz.scal[S_ALPHA] : 0.0, f_beta = FUSE ? fz.scal[S_BETA] : 0.0;
   double acc = 0.0;
   if ((int)blockIdx.x >= gmain) {
@@ -384,7 +394,11 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
   const int per = G / nch, extra = G - per * nch;
   const int seg = xcd * per + min(xcd, extra) + slot;      // blocks of one XCD get adjacent segments
-  const int64_t s0 = total * seg / G, s1 = total * (seg + 1) / G;
+  // plain: gridDim equal segments of the (tile, plane) sequence.  COMP: equal-COST segments (k_vcg_balance at set-up: a
+  // plane where the whole tile is air costs a fraction of one that computes) -- else the launch lasts as long as the
+  // marches that lie entirely in the liquid, however empty the rest of the domain is
+  int64_t s0 = total * seg / G, s1 = total * (seg + 1) / G;
+  if (COMP && c.seg_g == G) { s0 = c.seg[seg]; s1 = c.seg[seg + 1]; }
   const int64_t su = (int64_t)Ny * Nz, sv = (int64_t)(Ny + 1) * Nz, sw = (int64_t)Ny * W1, sc = c.plane();
   const T* const U = v.p[0];
   const T* const Vv = v.p[1];
@@ -507,7 +521,30 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
     auto ZL = [&](const V& a, const T* at) { T r = vm_from_left<T>(a[VEC - 1]); if (fixl) r = at[-1]; return r; };
     auto ZR = [&](const V& a, const T* at) { T r = vm_from_right<T>(a[0]); if (fixr) r = at[VEC]; return r; };
 
+    // COMP, tile level: byte (tile, x) of c.tw says whether the TILE computes anything at plane x -- all its vectors air
+    // otherwise (k_vcg_tile_flags); tw_at(x) packs the flags of planes x .. x+3 into bits 0-3.  Where a whole tile is air for a stretch of planes
+    // the march neither fetches nor stages those planes, skips the barrier and only stores its zeros: deep air costs
+    // 12 bytes per cell instead of 53.  Everything derived from it is uniform over the workgroup.
+    // the flags of 64 consecutive planes at a time: ONE wave-wide byte load + a ballot -> a 64-bit mask in scalar
+    // registers (a per-step load of the flag would be a memory round trip per step: in air that IS the step)
+    const unsigned char* const twp = COMP ? c.tw + (int64_t)tile * Nx : nullptr;
+    int wb = x0;                       // plane of bit 0 of the window
+    unsigned long long win = 0;
+    auto win_load = [&](int base) {
+      const int xx = base + (tid & 63);
+      const bool busy = xx < x1 && twp[xx] != 0;          // steps at or beyond x1 do not exist for this march
+      win = __builtin_amdgcn_ballot_w64(busy);
+      wb = base;
+    };
+    auto tw_at = [&](int xx) -> unsigned {                // bits 0-3: the tile computes something at plane xx .. xx+3
+      if (xx + 3 - wb >= 64) win_load(xx);
+      return (unsigned)((win >> (xx - wb)) & 0xfull);
+    };
+    if (COMP) win_load(x0);
+    unsigned tw_cur = COMP ? tw_at(x0) : 0xfu;
+    bool dirty = false;              // an image-reading step has run since the last barrier
     VmRegs<T, VEC> rg;
+    unsigned msk = 0, mskn = 0;      // mask bytes (+ COMP: class bits) of this step's vector; COMP: of the next step's too
     // ---- prologue: the images of planes x0-1, x0, x0+1 into ring slots 0, 1, 2; the volume samples of the first step
     {
       if constexpr (FUSE) {
@@ -522,23 +559,51 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
         fform(0, x0, ob, b0_, smem + BUF); fform(1, x0, ob, b1_, smem + BUF); fform(2, x0, ob, b2_, smem + BUF);
         fform(0, x0 + 1, oc, c0, smem + 2 * BUF); fform(1, x0 + 1, oc, c1, smem + 2 * BUF); fform(2, x0 + 1, oc, c2, smem + 2 * BUF);
       } else {
-        const Plane pa = fetch(x0 - 1), pb = fetch(x0), pc = fetch(x0 + 1);
+        // COMP: a plane is staged only if a step of this march that computes anything (tile not all air) taps it
+        Plane pa = Plane{}, pb = Plane{}, pc = Plane{};
+        if (tw_cur & 1u) pa = fetch(x0 - 1);
+        if (tw_cur & 3u) pb = fetch(x0);
+        if (tw_cur & 7u) pc = fetch(x0 + 1);
         if (dn != 0.0) return;                                   // uniform over the grid
-        publish(smem, pa); publish(smem + BUF, pb); publish(smem + 2 * BUF, pc);
+        if (tw_cur & 1u) publish(smem, pa);
+        if (tw_cur & 3u) publish(smem + BUF, pb);
+        if (tw_cur & 7u) publish(smem + 2 * BUF, pc);
       }
       const T* const q = C1 + (int64_t)x0 * sc + o_c;          // class 1 of this vector; class p at q + (p-1)*cs
-      rg.cm = vload<T, VEC>(q + 6 * cs - sc);
-      rg.exyc = vload<T, VEC>(q); rg.exzc = vload<T, VEC>(q + cs);
-      rg.fx = vload<T, VEC>(q + 2 * cs); rg.fy = vload<T, VEC>(q + 4 * cs); rg.fz = vload<T, VEC>(q + 5 * cs);
-      rg.cc = vload<T, VEC>(q + 6 * cs); rg.cym = vload<T, VEC>(q + 6 * cs - MFS_VM_NBR(c.pz));
       rg.czl = (T)0; rg.exzzr = (T)0; rg.eyzzr = (T)0;
       if (fixl) rg.czl = q[6 * cs - 1];
       if (fixr) { rg.exzzr = q[cs + VEC]; rg.eyzzr = q[3 * cs + VEC]; }
-      rg.exyp = vload<T, VEC>(q + sc); rg.exyyp = vload<T, VEC>(q + MFS_VM_NBR(c.pz));
-      rg.exzp = vload<T, VEC>(q + cs + sc);
-      rg.eyzc = vload<T, VEC>(q + 3 * cs); rg.eyzyp = vload<T, VEC>(q + 3 * cs + MFS_VM_NBR(c.pz));
+      if constexpr (COMP) {
+        // the step's class first (one more dependent round trip per march, behind the plane fetches already in flight)
+        msk = vm_mask<VEC>(MP + (int64_t)x0 * sc + o_c);
+        mskn = vm_mask<VEC>(MP + (int64_t)min(x0 + 1, Nx - 2) * sc + o_c);
+        const unsigned cl = (msk >> 4) & 3u;
+        const T cv = cl == kVmClsOne ? bulk : (T)0;
+        V k;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) k[j] = cv;
+        rg.cm = k; rg.exyc = k; rg.exzc = k; rg.fx = k; rg.fy = k; rg.fz = k; rg.cc = k; rg.cym = k;
+        rg.exyp = k; rg.exyyp = k; rg.exzp = k; rg.eyzc = k; rg.eyzyp = k;
+        if (cl == 0) {
+          rg.cm = vload<T, VEC>(q + 6 * cs - sc);
+          rg.exyc = vload<T, VEC>(q); rg.exzc = vload<T, VEC>(q + cs);
+          rg.fx = vload<T, VEC>(q + 2 * cs); rg.fy = vload<T, VEC>(q + 4 * cs); rg.fz = vload<T, VEC>(q + 5 * cs);
+          rg.cc = vload<T, VEC>(q + 6 * cs); rg.cym = vload<T, VEC>(q + 6 * cs - c.pz);
+          rg.exyp = vload<T, VEC>(q + sc); rg.exyyp = vload<T, VEC>(q + c.pz);
+          rg.exzp = vload<T, VEC>(q + cs + sc);
+          rg.eyzc = vload<T, VEC>(q + 3 * cs); rg.eyzyp = vload<T, VEC>(q + 3 * cs + c.pz);
+        }
+      } else {
+        rg.cm = vload<T, VEC>(q + 6 * cs - sc);
+        rg.exyc = vload<T, VEC>(q); rg.exzc = vload<T, VEC>(q + cs);
+        rg.fx = vload<T, VEC>(q + 2 * cs); rg.fy = vload<T, VEC>(q + 4 * cs); rg.fz = vload<T, VEC>(q + 5 * cs);
+        rg.cc = vload<T, VEC>(q + 6 * cs); rg.cym = vload<T, VEC>(q + 6 * cs - MFS_VM_NBR(c.pz));
+        rg.exyp = vload<T, VEC>(q + sc); rg.exyyp = vload<T, VEC>(q + MFS_VM_NBR(c.pz));
+        rg.exzp = vload<T, VEC>(q + cs + sc);
+        rg.eyzc = vload<T, VEC>(q + 3 * cs); rg.eyzyp = vload<T, VEC>(q + 3 * cs + MFS_VM_NBR(c.pz));
+      }
     }
-    unsigned msk = MFS_VM_MK(vm_mask<VEC>(MP + (int64_t)x0 * sc + o_c));
+    if constexpr (!COMP) msk = MFS_VM_MK(vm_mask<VEC>(MP + (int64_t)x0 * sc + o_c));
     MFS_VM_STAMP(0);                                             // prologue
 
     for (int x = x0; x < x1; ++x) {
@@ -549,11 +614,19 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       T* const bw = smem + ((k + 3) % RING) * BUF;             // plane x+2 (written at the end of this step)
       // ---- (1) ONE barrier per plane: plane x+1's images (published at the end of the previous step) are complete,
       //      and nobody reads plane x-2's slot any more (it is written at the end of this step)
-      MFS_VISC_LDS_BARRIER();
+      // plain: every step.  COMP: only when this step reads the images (it must see plane x+1, staged at the end of the
+      // previous step), or stages a plane into a slot that somebody may still be reading (an image-reading step ran since
+      // the last barrier)
+      const bool reads = !COMP || (tw_cur & 1u) != 0;
+      const bool stage = (x + 2 <= x1) && (!COMP || (tw_cur & 0xeu) != 0);
+      if (reads || (stage && dirty)) { MFS_VISC_LDS_BARRIER(); dirty = false; }
+      if (COMP && reads) dirty = true;
+      unsigned tw_nxt = 0xfu;
+      if (COMP) tw_nxt = x + 1 < x1 ? tw_at(x + 1) : 0u;
       MFS_VM_STAMP(1);                                           // barrier
       // ---- (2) in flight for the whole step: own rows and halo vectors of plane x+2 (clamped at the end: unused)
       // (the last two steps of a march need no further plane, its last step no further class samples: wave-uniform skips)
-      const bool need_plane = x + 2 <= x1, more = x + 1 < x1;
+      const bool need_plane = stage, more = x + 1 < x1;
       Plane pn = Plane{};
       const bool own_n = x + 2 < x1;                              // FUSE: plane x+2 is one of this march's own
       CompLd fl = CompLd{}, fl1 = CompLd{}, fl2 = CompLd{};
@@ -572,6 +645,14 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       // ---- (3) u rows.  Every velocity operand comes from the images (the ring is the register file of the march:
       //      nothing velocity is carried across steps); the registers of the class samples only this phase reads take
       //      the next step's afterwards (a whole step in flight)
+      // COMP: a wave whose 64 vectors are ALL air at this step (every class sample 0: wave-uniform, one ballot) skips the
+      // image reads and the rows of the step -- with all seven volumes 0 every coefficient of the three rows is 0 and
+      // q = 0 whatever the (finite) velocities are.  The skipped arithmetic would have produced +-0 (the sign following
+      // the operands' signs) or NaN for a non-finite operand; the skip stores +0: equal in value (==), not in the sign
+      // bit of a zero.  Planes are still fetched and published (neighbouring waves tap them), q is still stored.
+      const bool skip = COMP && (!reads || __builtin_amdgcn_ballot_w64(((msk >> 4) & 3u) != kVmClsZero) == 0);
+      V qu = V{};
+      if (!skip) {
       rg.um = vload<T, VEC>(bm + lu); rg.uc = vload<T, VEC>(bc + lu); rg.up = vload<T, VEC>(bn + lu);
       rg.uyp = vload<T, VEC>(bc + lu + Nz); rg.uym = vload<T, VEC>(bc + lu - Nz);
       rg.uzl = ZL(rg.uc, bc + lu); rg.uzr = ZR(rg.uc, bc + lu);
@@ -581,23 +662,30 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       rg.wm = vload<T, VEC>(bm + 2 * SU + lu); rg.wmzr = ZR(rg.wm, bm + 2 * SU + lu);
       { const T t = vm_from_right<T>(rg.exzc[0]); rg.exzzr = fixr ? rg.exzzr : t; }      // EXZ[x, y, z0+VEC]
       MFS_VM_STAMP(3);                                           // u: image reads (issued and landed)
-      V qu;
       MFS_VM_ROWS_BEGIN();
       vm_row<T, VEC, 0>(rg, k1, k2, msk, qu, first, last, active, acc);
       MFS_VM_ROWS_END();
+      }
       MFS_VM_STAMP(4);                                           // u: rows (includes the wait for this step's class samples)
       if (active) vm_store<T, VEC, true, NT>(ox + (int64_t)x * su + o_uv, qu, first, last);
       MFS_VM_PIN();
-      V fxn = V{}, ccn = V{}, exyypn = V{};
+      // COMP: the next step's class (its mask word has been in flight for a whole step) and the constant that stands
+      // for every sample of a ZERO / ONE vector; only MIXED vectors (ldn) issue class loads -- exec-masked, lane by lane
+      const unsigned cln = COMP ? ((mskn >> 4) & 3u) : 0u;
+      const bool ldn = more && cln == 0;
+      V kv;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) kv[j] = cln == kVmClsOne ? bulk : (T)0;
+      V fxn = kv, ccn = kv, exyypn = kv;
       T exzzrn = (T)0;
-      if (more) {
-        fxn = MFS_VM_LD1(qn + 2 * cs); ccn = MFS_VM_LD2(qn + 6 * cs); exyypn = vload<T, VEC>(qn + MFS_VM_NBR(c.pz));
-        if (fixr) exzzrn = qn[cs + VEC];
-      }
+      if (ldn) { fxn = MFS_VM_LD1(qn + 2 * cs); ccn = MFS_VM_LD2(qn + 6 * cs); exyypn = vload<T, VEC>(qn + MFS_VM_NBR(c.pz)); }
+      if (more && fixr) exzzrn = qn[cs + VEC];
       if constexpr (FUSE) if (need_plane) { fform(0, x + 2, own_n, fl, bw); if (!MFS_VM_FUSE_TOP) fl1 = fload(1, x + 2, own_n); }
       MFS_VM_PIN();
       MFS_VM_STAMP(5);                                           // u: store + issue of the next step's samples
       // ---- (4) v rows
+      V qv = V{};
+      if (!skip) {
       rg.vc = vload<T, VEC>(bc + SU + lu); rg.vp = vload<T, VEC>(bn + SU + lu); rg.vm = vload<T, VEC>(bm + SU + lu);
       rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vym = vload<T, VEC>(bc + SU + lu - Nz);
       rg.vzl = ZL(rg.vc, bc + SU + lu); rg.vzr = ZR(rg.vc, bc + SU + lu);
@@ -612,25 +700,27 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       }
       { const T t = vm_from_right<T>(rg.eyzc[0]); rg.eyzzr = fixr ? rg.eyzzr : t; }      // EYZ[x, y, z0+VEC]
       MFS_VM_STAMP(6);                                           // v: image reads
-      V qv;
       MFS_VM_ROWS_BEGIN();
       vm_row<T, VEC, 1>(rg, k1, k2, msk, qv, first, last, active, acc);
       MFS_VM_ROWS_END();
+      }
       MFS_VM_STAMP(7);                                           // v: rows
       if (active) vm_store<T, VEC, true, NT>(oy + (int64_t)x * sv + o_uv, qv, first, last);
       MFS_VM_PIN();
-      V fyn = V{}, cymn = V{}, exypn = V{};
+      V fyn = kv, cymn = kv, exypn = kv;
       T eyzzrn = (T)0;
-      unsigned mskn = 0;
+      unsigned mskl = 0;               // plain: the next step's mask bytes; COMP: those of the step after it
+      if (ldn) { fyn = MFS_VM_LD1(qn + 4 * cs); cymn = vload<T, VEC>(qn + 6 * cs - MFS_VM_NBR(c.pz)); exypn = MFS_VM_LD2(qn + sc); }
       if (more) {
-        fyn = MFS_VM_LD1(qn + 4 * cs); cymn = vload<T, VEC>(qn + 6 * cs - MFS_VM_NBR(c.pz)); exypn = MFS_VM_LD2(qn + sc);
         if (fixr) eyzzrn = qn[3 * cs + VEC];
-        mskn = MFS_VM_MK(vm_mask<VEC>(mqn));
+        mskl = MFS_VM_MK(vm_mask<VEC>(COMP ? MP + (int64_t)min(x + 2, Nx - 2) * sc + o_c : mqn));
       }
       if constexpr (FUSE) if (need_plane) { fform(1, x + 2, own_n, fl1, bw); if (!MFS_VM_FUSE_TOP) fl2 = fload(2, x + 2, own_n); }
       MFS_VM_PIN();
       MFS_VM_STAMP(8);                                           // v: store + issue
       // ---- (5) w rows
+      V qw = V{};
+      if (!skip) {
       rg.wc = vload<T, VEC>(bc + 2 * SU + lu); rg.wp = vload<T, VEC>(bn + 2 * SU + lu); rg.wm = vload<T, VEC>(bm + 2 * SU + lu);
       rg.wyp = vload<T, VEC>(bc + 2 * SU + lu + Nz);
       {
@@ -645,24 +735,24 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       rg.vyp = vload<T, VEC>(bc + SU + lu + Nz); rg.vypzl = ZL(rg.vyp, bc + SU + lu + Nz);
       { const T t = vm_from_left<T>(rg.cc[VEC - 1]); rg.czl = fixl ? rg.czl : t; }        // C[x, y, z0-1]
       MFS_VM_STAMP(9);                                           // w: image reads
-      V qw;
       MFS_VM_ROWS_BEGIN();
       vm_row<T, VEC, 2>(rg, k1, k2, msk, qw, first, last, active, acc);
       MFS_VM_ROWS_END();
+      }
       MFS_VM_STAMP(10);                                          // w: rows
       if (active) vm_store<T, VEC, false, NT>(oz + (int64_t)x * sw + o_w, qw, first, last);
       MFS_VM_PIN();
-      V fzn = V{}, exzpn = V{}, eyzcn = V{}, eyzypn = V{};
+      V fzn = kv, exzpn = kv, eyzcn = kv, eyzypn = kv;
       T czln = (T)0;
-      if (more) {
+      if (ldn) {
         fzn = MFS_VM_LD1(qn + 5 * cs); exzpn = MFS_VM_LD1(qn + cs + sc); eyzcn = MFS_VM_LD2(qn + 3 * cs);
         eyzypn = vload<T, VEC>(qn + 3 * cs + MFS_VM_NBR(c.pz));
-        if (fixl) czln = qn[6 * cs - 1];
       }
+      if (more && fixl) czln = qn[6 * cs - 1];
       MFS_VM_PIN();
       // ---- (6) plane x+2 into its slot (its loads have had the whole step); next step's class samples take over
       static_assert(!FUSE || RING == 4, "the fused form writes plane x+2's slot while the step reads the others");
-      if (RING == 3 && need_plane) MFS_VISC_LDS_BARRIER();      // plane x+2 reuses plane x-1's slot: everybody has read it
+      if (RING == 3 && need_plane && reads) { MFS_VISC_LDS_BARRIER(); dirty = false; }      // plane x+2 reuses plane x-1's slot: everybody has read it
       if (need_plane) { if constexpr (FUSE) fform(2, x + 2, own_n, fl2, bw); else publish(bw, pn); }
       MFS_VM_STAMP(11);                                          // w: store + issue, publish of plane x+2 (waits for its loads)
       rg.cm = rg.cc; rg.cc = ccn;
@@ -670,9 +760,10 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       rg.fx = fxn; rg.exyyp = exyypn; rg.exzzr = exzzrn;
       rg.fy = fyn; rg.cym = cymn; rg.eyzzr = eyzzrn;
       rg.fz = fzn; rg.eyzc = eyzcn; rg.eyzyp = eyzypn; rg.czl = czln;
-      msk = mskn;
+      if constexpr (COMP) { msk = mskn; mskn = mskl; } else msk = mskl;
+      tw_cur = tw_nxt;
     }
-    MFS_VISC_LDS_BARRIER();      // the next march stages into the ring while a slow wave may still read this one's planes
+    if (!COMP || dirty) MFS_VISC_LDS_BARRIER();      // the next march stages into the ring while a slow wave may still read this one's planes
   }
 #ifdef MFS_VM_STAMPS
   if (blockIdx.x < 64 && (tid & 63) == 0) {

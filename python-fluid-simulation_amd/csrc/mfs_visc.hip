@@ -238,6 +238,14 @@ struct Compact {
   const void* vol[8];           // state dtype; [0] (e,e,e) unused
   const unsigned char* msk;     // one byte per compact index: bit c = the face of component c there is not solid
                                 // (`sphi >= 0` at the three face classes 3 (e,o,o), 5 (o,e,o), 6 (o,o,e))
+  const unsigned char* tw;      // compressed class access, tile level: byte (tile, x) != 0: the march tile computes something
+                                // at plane x (k_vcg_tile_flags); built for tiles of `tw_block` vectors
+  int tw_block;
+  const int* seg;               // ... and the cost-balanced cut of the (tile, plane) sequence into seg_g segments (k_vcg_balance)
+  int seg_g;
+  const void* bulk;             // ONE value of the state dtype: the largest volume sample of the set-up (what a sub-cell
+                                // deep inside the liquid carries: 1 up to the rounding of lvol / (cell_vol / 8)) -- the
+                                // constant of the compressed class access' second uniform class
   int N[3];
   int py, pz;                   // row / element pitch (see above)
   __host__ __device__ int dim(int p, int ax) const { return N[ax] + (((p >> (2 - ax)) & 1) ? 0 : 1); }
@@ -267,6 +275,135 @@ k_vcg_setup(int Nx, int Ny, int Nz, int py, int pz, const void* sphi, int sdt, c
     const unsigned bit = 1u << (p == 3 ? 0 : (p == 5 ? 1 : 2));
     atomicOr(reinterpret_cast<unsigned*>(mp + (ci & ~(int64_t)3)), bit << (8 * (int)(ci & 3)));
   }
+}
+
+// the largest positive volume sample over the seven class arrays -> *out (bit pattern order = value order for positive
+// floats: one unsigned atomic max per wave)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_vcg_bulk_value(Compact c, T* out) {
+  typedef typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type U;
+  const int64_t n = c.stored();
+  U best = 0;
+  for (int p = 1; p < 8; ++p) {
+    const T* a = (const T*)c.vol[p];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const T v = a[i];
+      if (v > (T)0) { const U b = __builtin_bit_cast(U, v); best = b > best ? b : best; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    U other;
+    if (sizeof(T) == 4) other = (U)__shfl_xor((unsigned)best, o, 64);
+    else other = (U)(((unsigned long long)__shfl_xor((unsigned)((unsigned long long)best >> 32), o, 64) << 32) | __shfl_xor((unsigned)best, o, 64));
+    best = other > best ? other : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != 0) atomicMax(reinterpret_cast<U*>(out), best);
+}
+
+// Compressed class access of the x-marching kernel (mfs_vcg_march.h, COMP): the class of every interior z-vector -- are
+// ALL class samples its step loads +0.0 (bit 4), all exactly the set-up's bulk value (bit 5), or anything else (neither)? -- into bits 4-5
+// of the mask byte of the vector's first cell (every reader of the mask bytes extracts single bits 0-2).  Bit patterns
+// are compared (a -0.0 is "anything else"), so the constant that stands for a load IS what the load returns.  Runs behind
+// k_vcg_setup in the same stream, once per set-up.
+template <typename T> __device__ __forceinline__ bool vcg_is_pos_zero(T v);
+template <> __device__ __forceinline__ bool vcg_is_pos_zero<float>(float v) { return __float_as_uint(v) == 0u; }
+template <> __device__ __forceinline__ bool vcg_is_pos_zero<double>(double v) { return __double_as_longlong(v) == 0ll; }
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_vcg_classify(Compact c, unsigned char* mp) {
+  const int Nx = c.N[0], Ny = c.N[1], nzv = c.N[2] / VEC;
+  const int64_t total = (int64_t)(Nx - 2) * (Ny - 2) * nzv;
+  const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (iv >= total) return;
+  const int zv = (int)(iv % nzv), y = 1 + (int)((iv / nzv) % (Ny - 2)), x = 1 + (int)(iv / ((int64_t)nzv * (Ny - 2)));
+  const int64_t base = c.idx(x, y, zv * VEC), sc = c.plane();
+  bool zero = true, one = true;
+  const T bulk = *(const T*)c.bulk;
+  auto chk = [&](int p, int64_t off) {
+    const T* a = (const T*)c.vol[p] + base + off;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { const T v = a[j]; zero = zero && vcg_is_pos_zero<T>(v); one = one && v == bulk; }
+  };
+#pragma unroll
+  for (int p = 1; p < 8; ++p) chk(p, 0);
+  chk(7, -sc); chk(7, -c.pz);          // C at x-1, y-1
+  chk(1, sc); chk(1, c.pz);            // EXY at x+1, y+1
+  chk(2, sc);                          // EXZ at x+1
+  chk(4, c.pz);                        // EYZ at y+1
+  mp[base] = (unsigned char)((mp[base] & 0x0f) | (zero ? 0x10 : (one ? 0x20 : 0)));
+}
+
+// tile flags of the marching kernel (see Compact::tw): one WAVE per (tile, x) decides whether the tile computes anything
+// at plane x (any vector not all air) -> flag byte (0 at the two boundary planes: no step there)
+template <int VEC>
+__global__ void __launch_bounds__(256)
+k_vcg_tile_flags(Compact c, int block, unsigned char* flags) {
+  const int Nx = c.N[0], Ny = c.N[1], nzv = c.N[2] / VEC;
+  const int ipp = (Ny - 2) * nzv, tiles = (ipp + block - 1) / block;
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (w >= (int64_t)tiles * Nx) return;
+  const int tile = (int)(w / Nx), x = (int)(w - (int64_t)tile * Nx);
+  bool busy = false;
+  if (x >= 1 && x <= Nx - 2) {
+    const int v1 = min(ipp, (tile + 1) * block);
+    for (int it = tile * block + lane; it < v1; it += kWave) {
+      const int yy = it / nzv, zv = it - yy * nzv;
+      busy = busy || ((c.msk[c.idx(x, yy + 1, zv * VEC)] >> 4) & 3u) != 1u;
+    }
+  }
+  const bool any = __builtin_amdgcn_ballot_w64(busy) != 0;
+  if (lane == 0) flags[w] = any ? 1 : 0;
+}
+
+// Cost-balanced segments of the march's (tile, plane) sequence (tile-major, planes 1 .. Nx-2): item cost kVmCostBusy
+// where the tile computes something at the plane, 1 where it is all air.  seg[k] = the item whose cost interval holds
+// total * k / G; seg[G] = n.  ONE block: chunk sums, a scan over the 1024 chunks, then every thread walks its chunk.
+constexpr int kVmCostBusy = 6;
+__global__ void __launch_bounds__(1024)
+k_vcg_balance(const unsigned char* flags, int tiles, int Nx, int G, int* seg) {
+  const int np = Nx - 2;
+  const int64_t n = (int64_t)tiles * np;
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024, i0 = min(n, (int64_t)t * chunk), i1 = min(n, i0 + chunk);
+  auto cost = [&](int64_t i) -> long long { const int64_t tl = i / np; return flags[tl * Nx + 1 + (i - tl * np)] ? kVmCostBusy : 1; };
+  long long sum = 0;
+  for (int64_t i = i0; i < i1; ++i) sum += cost(i);
+  __shared__ long long s_pre[1024];
+  s_pre[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const long long v = t >= o ? s_pre[t - o] : 0;
+    __syncthreads();
+    s_pre[t] += v;
+    __syncthreads();
+  }
+  const long long total = s_pre[1023];
+  long long p = s_pre[t] - sum;                            // cost before this chunk
+  for (int64_t i = i0; i < i1; ++i) {
+    const long long c = cost(i);
+    long long k = (p * G + total - 1) / total;             // smallest k with total * k / G >= p  (or one below: checked)
+    for (; k < G && total * k / G < p + c; ++k)
+      if (total * k / G >= p) seg[k] = (int)i;
+    p += c;
+  }
+  if (t == 0) seg[G] = (int)n;
+}
+
+// census of the classes k_vcg_classify stored: out[0] ZERO, out[1] ONE, out[2] MIXED vectors (diagnostics / bench line)
+template <int VEC>
+__global__ void __launch_bounds__(256)
+k_vcg_class_census(Compact c, unsigned long long* out) {
+  const int Nx = c.N[0], Ny = c.N[1], nzv = c.N[2] / VEC;
+  const int64_t total = (int64_t)(Nx - 2) * (Ny - 2) * nzv;
+  const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (iv >= total) return;
+  const int zv = (int)(iv % nzv), y = 1 + (int)((iv / nzv) % (Ny - 2)), x = 1 + (int)(iv / ((int64_t)nzv * (Ny - 2)));
+  const unsigned k = (c.msk[c.idx(x, y, zv * VEC)] >> 4) & 3u;
+  atomicAdd(out + (k == 1 ? 0 : (k == 2 ? 1 : 2)), 1ull);
 }
 
 template <typename T>
@@ -747,6 +884,7 @@ k_vcg_apply_tiled(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
 }  // namespace mfs
 
 #include "mfs_vcg_march.h"
+#include "mfs_vcg_resident.h"
 
 using namespace mfs;
 
@@ -777,6 +915,16 @@ struct mfs_vcg3d {
   void* diag;      // its diagonal (n elements, built by setup when the flag is on)
   double* part_rz; // its r.z partials
   bool diag_ready;
+  // small grids: the whole loop as one resident launch per batch (mfs_vcg_resident.h): 1 / 0 / -1 auto (MFS_VISC_RESIDENT)
+  int resident;
+  VResPlan res;
+  u64 *res_ar, *res_mirror;
+  unsigned res_epoch;                                  // episode tags handed out so far
+  u64 res_timeout_ticks, res_first_timeout_ticks;      // read once at creation
+  int res_drop_wg;                                     // MFS_VRES_TEST_DROP_WG: fault injection, tests only
+  int res_creg;                                        // MFS_VRES_CREG (default 1): volume samples in registers where they fit
+  int compress;    // 1 (default; MFS_VISC_COMPRESS): the march reads the class arrays only for MIXED vectors (k_vcg_classify)
+  int march_nt;    // MFS_VISC_MARCH_NT: nontemporal class loads / q stores (-1 auto by size), read at creation
   int fuse;        // 1: mfs_vcg3d_iterate / solve fold the direction and x updates into the march (2 launches per iteration); default 0
   void* d2;        // ping-pong partner of the bound d for that loop (n elements, zero outside the faces the loop writes)
   bool fused_run;  // the fused loop has run since begin: x lags by one update, d_j may sit in d2 (vcg_home settles both)
@@ -792,6 +940,15 @@ static int64_t class_count(const int64_t gres[3], int /*p*/) {
 static size_t class_stride_bytes(const int64_t gres[3], int dt) {
   const size_t pad = (size_t)std::max(256, env_int("MFS_VISC_CLASS_PAD", 4096)) / 256 * 256;
   return align_up((size_t)class_count(gres, 0) * dtype_size(dt), 4096) + pad;
+}
+
+constexpr int kVmMaxSegs = 4096;       // workgroups of a march launch, at most (cus x blocks per CU)
+
+// bytes of the marching kernel's tile words: (tiles of >= 256 vectors per plane) x Nx
+static size_t tile_words_bytes(const int64_t gres[3], int dt) {
+  const int64_t vec = dt == MFS_F32 ? 4 : 2;
+  const int64_t tiles = (gres[1] * (gres[2] / vec + 1) + 255) / 256 + 1;
+  return align_up((size_t)(tiles * (gres[0] + 1)), 4096);
 }
 
 static int check_gres(const int64_t gres[3]) {
@@ -873,7 +1030,7 @@ static bool vcg_march_ok(const mfs_vcg3d* h, const void* v, const void* out) {
   return true;
 }
 
-template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock, int RING = kVmRing>
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, int BLOCK = kVmBlock, int RING = kVmRing, bool COMP = false>
 static int vcg_march_launch_blk(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
                                 int* nparts, const VmFuse<T>* fz) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
@@ -886,11 +1043,11 @@ static int vcg_march_launch_blk(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double*
   const int g0 = h->skip_top_x ? 0 : vslab_grid(b0), g1 = vslab_grid(b1), g2 = vslab_grid(b2);
   static bool attr_set = false;        // per instantiation: more than the default 64 KB of dynamic LDS
   if (!attr_set) {
-    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK, RING>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK, RING, COMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kVmMaxLds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK, RING>), dim3(gmain + g0 + g1 + g2), dim3(BLOCK), lds, st, h->cp, h->k1,
+  hipLaunchKernelGGL((k_vcg_apply_march<T, VEC, WAVES, NT, FUSE, BLOCK, RING, COMP>), dim3(gmain + g0 + g1 + g2), dim3(BLOCK), lds, st, h->cp, h->k1,
                      h->k2, vv, ob + h->off[0], ob + h->off[1], ob + h->off[2], gmain, b0, b1, b2, g0, g1, partial, done,
                      fz ? *fz : VmFuse<T>{});
   MFS_LAUNCH_CHECK();
@@ -898,26 +1055,32 @@ static int vcg_march_launch_blk(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double*
   return MFS_OK;
 }
 
-template <typename T, int VEC, int WAVES, int NT, bool FUSE = false>
+template <typename T, int VEC, int WAVES, int NT, bool FUSE = false, bool COMP = false>
 static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
                                int* nparts, const VmFuse<T>* fz = nullptr) {
   if constexpr (VEC == VecOf<T>::N && WAVES == MFS_VMARCH_MIN_WAVES) {
     const int geom = vcg_march_geom<T, VEC>(h);
-    if (geom == 5124) return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512, 4>(h, vv, ob, partial, done, st, nparts, fz);
+    if (geom == 5124) return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512, 4, COMP>(h, vv, ob, partial, done, st, nparts, fz);
     if constexpr (!FUSE) {
-      if (geom == 5123) return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512, 3>(h, vv, ob, partial, done, st, nparts, fz);
+      if (geom == 5123) return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 512, 3, COMP>(h, vv, ob, partial, done, st, nparts, fz);
     }
   }
-  return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 256, 4>(h, vv, ob, partial, done, st, nparts, fz);
+  return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 256, 4, COMP>(h, vv, ob, partial, done, st, nparts, fz);
 }
 
 template <typename T, int VEC, int WAVES>
 static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
                             int* nparts) {
   // nontemporal class loads / q stores once operand, result and classes (13 arrays) exceed the Infinity Cache
-  // (MFS_VISC_MARCH_NT = 0 / 1 overrides; read per launch so that an A/B can toggle it on one engine)
-  const int knob = env_int("MFS_VISC_MARCH_NT", -1);
+  // (MFS_VISC_MARCH_NT = 0 / 1 overrides, read at engine creation)
+  const int knob = h->march_nt;
   const bool nt = knob < 0 ? (13.0 * (double)h->g.N[0] * h->g.N[1] * h->g.N[2] * sizeof(T) > 200e6) : (knob != 0);
+  if constexpr (VEC == VecOf<T>::N && WAVES == MFS_VMARCH_MIN_WAVES) {
+    // compressed class access (k_vcg_classify / k_vcg_tile_words ran at set-up, for this very tile size): fewer bytes
+    if (h->compress && h->cp.tw_block > 0 && h->cp.tw_block == vcg_march_geom<T, VEC>(h) / 10)
+      return nt ? vcg_march_launch_nt<T, VEC, WAVES, 5, false, true>(h, vv, ob, partial, done, st, nparts)
+                : vcg_march_launch_nt<T, VEC, WAVES, 0, false, true>(h, vv, ob, partial, done, st, nparts);
+  }
   return nt ? vcg_march_launch_nt<T, VEC, WAVES, 5>(h, vv, ob, partial, done, st, nparts)
             : vcg_march_launch_nt<T, VEC, WAVES, 0>(h, vv, ob, partial, done, st, nparts);
 }
@@ -935,7 +1098,7 @@ static int vcg_march_fused(mfs_vcg3d* h, const void* d_prev, void* d_cur, hipStr
   VmFuse<T> fz;
   for (int a = 0; a < 3; ++a) { fz.r[a] = rb + h->off[a]; fz.dn[a] = dc + h->off[a]; fz.x[a] = xb + h->off[a]; }
   fz.scal = h->c.scal;
-  const int knob = env_int("MFS_VISC_MARCH_NT", -1);
+  const int knob = h->march_nt;
   const bool nt = knob < 0 ? (13.0 * (double)h->g.N[0] * h->g.N[1] * h->g.N[2] * sizeof(T) > 200e6) : (knob != 0);
   return nt ? vcg_march_launch_nt<T, VEC, MFS_VMARCH_MIN_WAVES, 5, true>(h, vv, (T*)h->c.q, h->c.part_dq, h->c.scal + S_DONE, st, nparts, &fz)
             : vcg_march_launch_nt<T, VEC, MFS_VMARCH_MIN_WAVES, 0, true>(h, vv, (T*)h->c.q, h->c.part_dq, h->c.scal + S_DONE, st, nparts, &fz);
@@ -1348,6 +1511,10 @@ size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   tot += align_up((size_t)mfs_vcg3d_dofs(gres) * dtype_size(dt), 4096);   // partner of d (fused loop)
   tot += align_up((size_t)mfs_vcg3d_dofs(gres) * dtype_size(dt), 4096);   // diagonal (Jacobi loop)
   tot += align_up((size_t)kMaxPartials * 8, 4096);                        // r.z partials (Jacobi loop)
+  tot += vres_ws_bytes(mfs_vcg3d_dofs(gres), dtype_size(dt));             // resident loop: records + face mirror (0 if too big)
+  tot += 4096;                                                            // the bulk volume value (compressed class access)
+  tot += tile_words_bytes(gres, dt);                                      // its tile words
+  tot += align_up((size_t)(kVmMaxSegs + 1) * sizeof(int), 4096);          // ... and the cost-balanced segment starts
   return tot;
 }
 
@@ -1382,9 +1549,35 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->d2 = p; p += align_up((size_t)h->n * dtype_size(dt), 4096);
   h->diag = p; p += align_up((size_t)h->n * dtype_size(dt), 4096);
   h->part_rz = (double*)p; p += align_up((size_t)kMaxPartials * 8, 4096);
+  h->cp.bulk = p; p += 4096;
+  h->cp.tw = (const unsigned char*)p; p += tile_words_bytes(gres, dt);
+  h->cp.tw_block = 0;
+  h->cp.seg = (const int*)p; p += align_up((size_t)(kVmMaxSegs + 1) * sizeof(int), 4096);
+  h->cp.seg_g = 0;
+  h->resident = env_int("MFS_VISC_RESIDENT", -1);
+  h->res = VResPlan{};
+  h->res_ar = nullptr; h->res_mirror = nullptr; h->res_epoch = 0;
+  if (vres_ws_bytes(h->n, dtype_size(dt)) > 0) {
+    h->res_ar = (u64*)p;
+    h->res_mirror = (u64*)(p + align_up((size_t)kVResRing * kVResMaxW * kVResRecStride * 8, 4096));
+    p += vres_ws_bytes(h->n, dtype_size(dt));
+    // as many workgroups as fit half the chip, fewer if the boxes then get too thin to be worth their halo
+    // as many workgroups as the chip has CUs at most (MFS_VRES_W caps it); fewer if the boxes then get too thin
+    const int wmax = std::max(1, std::min(std::min(kVResMaxW, h->c.cus), env_int("MFS_VRES_W", 256)));
+    int w0 = 1;
+    while (2 * w0 <= wmax) w0 *= 2;
+    for (int w = w0; w >= 16 && !h->res.ok; w /= 2)
+      h->res = vres_plan(h->g.N[0], h->g.N[1], h->g.N[2], dtype_size(dt), w, dt == MFS_F32 ? 6 : 4);
+  }
+  h->res_timeout_ticks = (u64)std::max(1, env_int("MFS_VRES_TIMEOUT_MS", 2000)) * 100000ull;      // wall clock: 100 MHz
+  h->res_first_timeout_ticks = (u64)std::max(1, env_int("MFS_VRES_FIRST_TIMEOUT_MS", 250)) * 100000ull;
+  h->res_drop_wg = env_int("MFS_VRES_TEST_DROP_WG", -1);
+  h->res_creg = env_int("MFS_VRES_CREG", 1);
   h->jacobi = env_int("MFS_VISC_JACOBI", 0);
   h->last_iters = 0;
   h->diag_ready = false;
+  h->compress = env_int("MFS_VISC_COMPRESS", 1);
+  h->march_nt = env_int("MFS_VISC_MARCH_NT", -1);
   h->fuse = env_int("MFS_VISC_FUSE", 0);   // measured slower than the three-launch loop: opt-in
   h->fused_run = false;
   h->grid_row = std::min(kMaxPartials / 3, h->c.cus * env_int("MFS_VISC_BLOCKS_PER_CU", 8));
@@ -1436,6 +1629,44 @@ int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int
                        h->cp.pz, sphi, sphi_dt, vol, vol_dt, (double*)v[1], (double*)v[2], (double*)v[3], (double*)v[4],
                        (double*)v[5], (double*)v[6], (double*)v[7], mp);
   MFS_LAUNCH_CHECK();
+  if (Nx >= 3 && Ny >= 3) {    // classes of the interior z-vectors for the march's compressed class access
+    const int vec = h->dt == MFS_F32 ? 4 : 2;
+    if (Nz % vec == 0 && Nz >= 2 * vec) {
+      MFS_HIP_TRY(hipMemsetAsync((void*)h->cp.bulk, 0, 8, (hipStream_t)stream));
+      const int gb = (int)std::min<int64_t>(1024, cdiv(h->cp.stored(), 256));
+      if (h->dt == MFS_F32) hipLaunchKernelGGL((k_vcg_bulk_value<float>), dim3(gb), dim3(256), 0, (hipStream_t)stream, h->cp, (float*)h->cp.bulk);
+      else hipLaunchKernelGGL((k_vcg_bulk_value<double>), dim3(gb), dim3(256), 0, (hipStream_t)stream, h->cp, (double*)h->cp.bulk);
+      const int64_t nvec = (int64_t)(Nx - 2) * (Ny - 2) * (Nz / vec);
+      if (h->dt == MFS_F32) hipLaunchKernelGGL((k_vcg_classify<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, mp);
+      else hipLaunchKernelGGL((k_vcg_classify<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, mp);
+      MFS_LAUNCH_CHECK();
+      // ... and the tile words, for the tile size the march will run with on this grid
+      const int geom = h->dt == MFS_F32 ? vcg_march_geom<float, 4>(h) : vcg_march_geom<double, 2>(h);
+      h->cp.tw_block = geom / 10;
+      if (h->cp.tw_block > 0) {
+        const int ipp = (Ny - 2) * (Nz / vec), tiles = (ipp + h->cp.tw_block - 1) / h->cp.tw_block;
+        const int64_t nt = (int64_t)tiles * Nx;
+        const int64_t gr[3] = {Nx, Ny, Nz};
+        MFS_REQUIRE((size_t)nt <= tile_words_bytes(gr, h->dt), "tile flags do not fit their workspace");
+        unsigned char* const flags = (unsigned char*)h->cp.tw;
+        if (vec == 4) hipLaunchKernelGGL((k_vcg_tile_flags<4>), dim3(cdiv(nt * kWave, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, h->cp.tw_block, flags);
+        else hipLaunchKernelGGL((k_vcg_tile_flags<2>), dim3(cdiv(nt * kWave, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, h->cp.tw_block, flags);
+        MFS_LAUNCH_CHECK();
+        // the cost-balanced cut for the grid the march will be launched with on this engine
+        const size_t ldsb = h->dt == MFS_F32 ? (size_t)(geom % 10) * 3 * (2 * Nz + h->cp.tw_block * 4) * 4
+                                             : (size_t)(geom % 10) * 3 * (2 * Nz + h->cp.tw_block * 2) * 8;
+        const int bpc = ldsb > 80 * 1024 ? 1 : h->march_bpc;
+        const int64_t total = (int64_t)tiles * (Nx - 2);
+        const int G = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * bpc));
+        h->cp.seg_g = 0;
+        if (G <= kVmMaxSegs && total < 0x7fffffff) {
+          hipLaunchKernelGGL(k_vcg_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, flags, tiles, Nx, G, (int*)h->cp.seg);
+          MFS_LAUNCH_CHECK();
+          h->cp.seg_g = G;
+        }
+      }
+    }
+  }
   h->k1 = scale * mu;          // `scale * mu * ...`      (left to right, as the reference evaluates it)
   h->k2 = 2 * scale * mu;      // `2 * scale * mu * ...`
   h->is_setup = true;
@@ -1652,6 +1883,64 @@ static int vcg_jac_iteration_z(mfs_vcg3d* h, hipStream_t st) {
 }
 }  // extern "C++"
 
+// the resident loop (mfs_vcg_resident.h): a grid whose state fits W workgroups' registers and LDS, the reference's plain
+// loop (no Jacobi, no fused / masked / slab form), a device with that many CUs
+static bool vcg_resident_ok(const mfs_vcg3d* h) {
+  return h->resident != 0 && h->res.ok && h->res_ar && !h->jacobi && !h->fuse && !h->mask_cg && !h->p2p && !h->skip_top_x &&
+         h->c.x && h->c.cus >= h->res.W;
+}
+
+extern "C++" {
+template <typename T>
+static int vcg_launch_resident(mfs_vcg3d* h, const VResArgs& a, hipStream_t st) {
+  const VResPlan& p = h->res;
+#define MFS_VRES_ONE(KCC, CRG)                                                                                   \
+  do {                                                                                                           \
+    MFS_HIP_TRY(hipFuncSetAttribute((const void*)k_vcg_resident<T, KCC, CRG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)kVResLdsMax));                                                          \
+    hipLaunchKernelGGL((k_vcg_resident<T, KCC, CRG>), dim3(p.W), dim3(kVResBlock), p.lds, st, a);                \
+  } while (0)
+  // volume samples in registers where KC cells' worth fit without spills (16 per cell, kept converted to fp64):
+  // 8-byte state up to 2 cells, 4-byte up to 3
+  const bool creg = h->res_creg != 0 && p.kc <= (sizeof(T) == 8 ? 2 : 3);
+  if (p.kc <= 1) { if (creg) MFS_VRES_ONE(1, true); else MFS_VRES_ONE(1, false); }
+  else if (p.kc == 2) { if (creg) MFS_VRES_ONE(2, true); else MFS_VRES_ONE(2, false); }
+  else if (p.kc == 3) { if (creg) MFS_VRES_ONE(3, true); else MFS_VRES_ONE(3, false); }
+  else if (p.kc == 4) MFS_VRES_ONE(4, false);
+  else MFS_VRES_ONE(6, false);
+#undef MFS_VRES_ONE
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+}  // extern "C++"
+
+static int vcg_iterate_resident(mfs_vcg3d* h, int64_t n, hipStream_t st) {
+  while (n > 0) {
+    const int nb = (int)std::min<int64_t>(n, 1 << 20);
+    if (h->res_epoch > 0xf0000000u - 2u * (unsigned)nb) {      // tags about to wrap: start over on clean tables
+      MFS_HIP_TRY(hipMemsetAsync(h->res_ar, 0, vres_ws_bytes(h->n, h->c.elt), st));
+      h->res_epoch = 0;
+    }
+    VResArgs a{};
+    a.x = h->c.x; a.r = h->c.r; a.q = h->c.q; a.d = h->c.d;
+    a.c = h->cp; a.k1 = h->k1; a.k2 = h->k2;
+    for (int c = 0; c < 3; ++c) a.off[c] = h->off[c];
+    a.Px = h->res.Px; a.Py = h->res.Py; a.bxm = h->res.bxm; a.bym = h->res.bym;
+    a.scal = h->c.scal; a.hist = h->c.hist; a.hist_cap = kHistCap;
+    a.n_iter = nb;
+    a.ar = h->res_ar; a.mirror = h->res_mirror;
+    a.tag0 = h->res_epoch + 1u;
+    a.timeout_ticks = h->res_timeout_ticks; a.first_timeout_ticks = h->res_first_timeout_ticks;
+    a.test_drop_wg = h->res_drop_wg;
+    int e = h->dt == MFS_F32 ? vcg_launch_resident<float>(h, a, st) : vcg_launch_resident<double>(h, a, st);
+    if (e) return e;
+    h->res_epoch += 2u * (unsigned)nb;
+    h->c.iter_enq += nb;
+    n -= nb;
+  }
+  return MFS_OK;
+}
+
 int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
@@ -1695,6 +1984,7 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
     }
     return MFS_OK;
   }
+  if (vcg_resident_ok(h)) return vcg_iterate_resident(h, n, st);
   // small problems: both vector phases, the r.r reduction and the bookkeeping in ONE launch whose workgroups exchange
   // their partial sums while resident (k_update_rdx, mfs_cg_core.h): 2 launches per iteration, no reduction tail
   const bool rdx = core_rdx_ok(h->c) && !h->p2p;
@@ -1751,7 +2041,8 @@ int mfs_vcg3d_poll(mfs_vcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
   if ((int)h->c.pinned[S_ERR] == kErrNotResident) {
     MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_ERR, 0, sizeof(double), st));
     MFS_HIP_TRY(hipMemsetAsync(h->c.scal + S_DONE, 0, sizeof(double), st));
-    h->c.rdx = 0;
+    if (vcg_resident_ok(h)) h->resident = 0;      // the resident loop did not get its workgroups: launch-per-phase from now on
+    else h->c.rdx = 0;
     h->c.iter_enq = (int64_t)h->c.pinned[S_ITERS];
     fresh = false;
   }
@@ -1800,6 +2091,34 @@ int mfs_vcg3d_finish(mfs_vcg3d* h, mfs_stream stream) {
 }
 
 // 1 / 0: fold the direction and x updates into the marching kernel (default 0; MFS_VISC_FUSE)
+int mfs_vcg3d_set_compress(mfs_vcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->compress = on ? 1 : 0;
+  return MFS_OK;
+}
+
+int mfs_vcg3d_class_census(mfs_vcg3d* h, int64_t counts_host[3], mfs_stream stream) {
+  MFS_REQUIRE(h && counts_host, "null argument");
+  MFS_REQUIRE(h->is_setup, "mfs_vcg3d_setup has not been called");
+  counts_host[0] = counts_host[1] = counts_host[2] = 0;
+  const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2], vec = h->dt == MFS_F32 ? 4 : 2;
+  if (Nx < 3 || Ny < 3 || Nz % vec != 0 || Nz < 2 * vec) return MFS_OK;       // no marching kernel, no classes
+  unsigned long long* dv = (unsigned long long*)h->part_rz;                   // scratch: 3 words of the Jacobi partials
+  hipStream_t st = (hipStream_t)stream;
+  MFS_HIP_TRY(hipStreamSynchronize(st));                                      // (diagnostic call: nothing may be using the scratch)
+  MFS_HIP_TRY(hipMemsetAsync(dv, 0, 3 * sizeof(unsigned long long), st));
+  const int64_t nvec = (int64_t)(Nx - 2) * (Ny - 2) * (Nz / vec);
+  if (vec == 4) hipLaunchKernelGGL((k_vcg_class_census<4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, dv);
+  else hipLaunchKernelGGL((k_vcg_class_census<2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, dv);
+  MFS_LAUNCH_CHECK();
+  unsigned long long host[3];
+  MFS_HIP_TRY(hipMemcpyAsync(host, dv, sizeof(host), hipMemcpyDeviceToHost, st));
+  MFS_HIP_TRY(hipStreamSynchronize(st));
+  MFS_HIP_TRY(hipMemsetAsync(dv, 0, 3 * sizeof(unsigned long long), st));
+  for (int k = 0; k < 3; ++k) counts_host[k] = (int64_t)host[k];
+  return MFS_OK;
+}
+
 int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on) {
   MFS_REQUIRE(h, "null handle");
   MFS_REQUIRE(!h->fused_run, "mfs_vcg3d_set_fuse inside a fused loop: call mfs_vcg3d_finish first");
@@ -1811,7 +2130,15 @@ int mfs_vcg3d_set_fuse(mfs_vcg3d* h, int on) {
 int mfs_vcg3d_loop_info(mfs_vcg3d* h) {
   if (!h) return 0;
   if (!h->c.x || !h->is_setup) return h->jacobi ? 4 : 0;
+  if (vcg_resident_ok(h)) return 8;
   return (vcg_fuse_ok(h) ? 1 : 0) | ((!h->jacobi && !vcg_fuse_ok(h) && core_rdx_ok(h->c) && !h->p2p) ? 2 : 0) | (h->jacobi ? 4 : 0);
+}
+
+// 1 / 0: allow the resident small-grid loop (default: on where the grid qualifies; env MFS_VISC_RESIDENT)
+int mfs_vcg3d_set_resident(mfs_vcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->resident = on ? 1 : 0;
+  return MFS_OK;
 }
 
 // OPT-IN Jacobi preconditioning of mfs_vcg3d_begin / iterate / solve (default off; env MFS_VISC_JACOBI=1): see mfs.h

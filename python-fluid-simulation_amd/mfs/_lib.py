@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("MFS_LIB") or os.path.join(_HERE, "libmfs_hip.so")   #
 MFS_F32, MFS_F64 = 0, 1
 MFS_OK, MFS_NOT_CONVERGED = 0, 1
 MFS_E_TIMEOUT, MFS_E_ZERODIV, MFS_E_NONFINITE = -4, -5, -6
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 # scalar slots of the CG engine's device block (include/mfs.h)
 S_DQ, S_RR, S_DELTA, S_TOL2, S_DONE, S_ITERS, S_ALPHA, S_BETA, S_LASTRR = range(9)
@@ -129,6 +129,9 @@ SIGNATURES = {
     "mfs_vcg3d_solve": (_i, [_p, _d, _i64, _i64, _p, _pi64]),
     "mfs_vcg3d_finish": (_i, [_p, _p]),
     "mfs_vcg3d_set_fuse": (_i, [_p, _i]),
+    "mfs_vcg3d_set_compress": (_i, [_p, _i]),
+    "mfs_vcg3d_set_resident": (_i, [_p, _i]),
+    "mfs_vcg3d_class_census": (_i, [_p, _pi64, _p]),
     "mfs_vcg3d_loop_info": (_i, [_p]),
     "mfs_vcg3d_set_merged": (_i, [_p, _i]),
     "mfs_vcg3d_set_jacobi": (_i, [_p, _i]),
@@ -158,6 +161,11 @@ SIGNATURES = {
     "mfs_density_advect3d": (_i, [_p, _i, _i64, _p, _i, _pi64, _pd, _pd, _pd, _i, _p]),
     "mfs_p2g_scatter3d": (_i, [_pi64, _pd, _pd, _pd, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _i, _p]),
     "mfs_p2g_normalize3d": (_i, [_i64, _p, _p, _i, _p]),
+    "mfs_particle_tiles3d": (_i64, [_pi64]),
+    "mfs_particle_tile_sort3d": (_i, [_pi64, _pd, _pd, _p, _i, _i64, _p, _p, _p, _p]),
+    "mfs_p2g_scatter3d_tiled": (_i, [_pi64, _pd, _pd, _pd, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _i, _p]),
+    "mfs_fluid_levelset3d_tiled": (_i, [_pi64, _pd, _pd, _d, _p, _i, _i64, _p, _p, _p, _i, _p]),
+    "mfs_fluid_volume3d_tiled": (_i, [_pi64, _pd, _pd, _p, _i, _d, _i64, _p, _p, _p, _i, _p]),
     "mfs_g2p_gather3d": (_i, [_pi64, _pd, _pd, _pd, _i, _p, _i, _p, _i, _p, _i, _i64, _p, _i, _p]),
     "mfs_fluid_levelset3d": (_i, [_pi64, _pd, _pd, _d, _p, _i, _i64, _p, _i, _p]),
     "mfs_fluid_volume3d": (_i, [_pi64, _pd, _pd, _p, _i, _d, _i64, _p, _i, _p]),

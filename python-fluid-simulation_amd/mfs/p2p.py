@@ -9,6 +9,7 @@ bench.py, "gloo" in the tests).  Inside the CG loop no collective is called.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -63,11 +64,18 @@ class P2PWindow:
                 st = self.lib.mfs_p2p_selftest(self.h, rnd, T.stream(), C.byref(ok), det)
             good = good and st == 0 and ok.value == 1
             self.detail = list(det)
+        # fault injection (tests / rehearsals of the downgrade path): MFS_P2P_SELFTEST_FAIL=1 fails it on every rank,
+        # =r<k> on rank k only -- the window then stays unused and the callers must fall back to the collective loop
+        inj = os.environ.get("MFS_P2P_SELFTEST_FAIL", "")
+        injected = inj == "1" or inj == f"r{self.rank}"
+        if injected:
+            good = False
         verdicts = [None] * self.world
         dist.all_gather_object(verdicts, bool(good), group=group)
         self.ok = all(verdicts)
         if not self.ok:
-            self.why = f"self-test failed on ranks {[r for r, v in enumerate(verdicts) if not v]} (detail {self.detail})"
+            self.why = (f"self-test failed on ranks {[r for r, v in enumerate(verdicts) if not v]} (detail {self.detail})"
+                        + (" [injected: MFS_P2P_SELFTEST_FAIL]" if inj else ""))
 
     @property
     def alloc_kind(self):

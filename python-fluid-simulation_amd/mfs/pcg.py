@@ -159,6 +159,13 @@ class PcgEngine:
         _lib.check(int(n), "mfs_pcg3d_history")
         return buf[: int(n)].copy()
 
+    def history_truncated(self):
+        """True when the solve ran past the history buffer (capacity mfs_pcg3d_history_capacity() doubles = 8 191 iterations):
+        history() then holds the LEADING entries only -- `iterations`, `delta`, alpha and beta come from the engine's scalar
+        block (poll()), never from the history, and stay exact"""
+        cap = int(self.lib.mfs_pcg3d_history_capacity())
+        return 2 * int(self.poll_raw()["iterations"]) + 1 > cap
+
     # -- single phases (multi-GPU driver) ------------------------------------------
     def phase_apply(self, xb, xe, first):
         _lib.check(self.lib.mfs_pcg3d_phase_apply(self.h, int(xb), int(xe), int(bool(first)), T.stream()),

@@ -88,13 +88,28 @@ class VcgEngine:
         """settle what the fused loop of `iterate` owes (last x update, d brought home); begin again before iterating on"""
         _lib.check(self.lib.mfs_vcg3d_finish(self.h, T.stream()), "mfs_vcg3d_finish")
 
+    def set_compress(self, on):
+        """compressed class access of the marching kernel (default on): bit-identical, fewer bytes where the liquid
+        volume is 0 or 1 over whole z-vectors"""
+        _lib.check(self.lib.mfs_vcg3d_set_compress(self.h, int(bool(on))), "mfs_vcg3d_set_compress")
+
+    def class_census(self):
+        """{"zero", "one", "mixed"}: z-vectors per class of the compressed class access (after setup)"""
+        out = _lib.i64x([0, 0, 0])
+        _lib.check(self.lib.mfs_vcg3d_class_census(self.h, out, T.stream()), "mfs_vcg3d_class_census")
+        return {"zero": int(out[0]), "one": int(out[1]), "mixed": int(out[2])}
+
     def set_fuse(self, on):
         _lib.check(self.lib.mfs_vcg3d_set_fuse(self.h, int(bool(on))), "mfs_vcg3d_set_fuse")
 
     def loop_info(self):
         """{"fused": iterate() runs the 2-launch loop with the direction and x updates folded into the marching kernel}"""
         b = int(self.lib.mfs_vcg3d_loop_info(self.h))
-        return {"fused": bool(b & 1), "merged_vector_phases": bool(b & 2), "jacobi": bool(b & 4)}
+        return {"fused": bool(b & 1), "merged_vector_phases": bool(b & 2), "jacobi": bool(b & 4), "resident": bool(b & 8)}
+
+    def set_resident(self, on):
+        """small grids: the whole CG loop as one resident launch per iterate() batch (default on where the grid qualifies)"""
+        _lib.check(self.lib.mfs_vcg3d_set_resident(self.h, int(bool(on))), "mfs_vcg3d_set_resident")
 
     def set_jacobi(self, on):
         """opt-in Jacobi preconditioning (NOT the reference's CG: fewer iterations, another residual history); takes effect
@@ -168,3 +183,10 @@ class VcgEngine:
         n = self.lib.mfs_vcg3d_history(self.h, buf.ctypes.data_as(C.POINTER(C.c_double)), cap, T.stream())
         _lib.check(int(n), "mfs_vcg3d_history")
         return buf[: int(n)].copy()
+
+    def history_truncated(self):
+        """True when the solve ran past the history buffer (capacity mfs_pcg3d_history_capacity() doubles = 8 191 iterations):
+        history() then holds the LEADING entries only -- `iterations`, `delta`, alpha and beta come from the engine's scalar
+        block (poll()), never from the history, and stay exact"""
+        cap = int(self.lib.mfs_pcg3d_history_capacity())
+        return 2 * int(self.poll_raw()["iterations"]) + 1 > cap

@@ -7,7 +7,9 @@ definitions (its `edict` containers are any objects with the same attributes); P
 HIP kernels behind the C ABI.  (The gravity step, ipynb:4608, is `grid.y.v += -10 * dt` -- a tensor
 expression.)"""
 import math
+import os
 
+import numpy as np
 import torch
 
 from mfs import _lib, tensors as T
@@ -65,6 +67,51 @@ def _f3(a):
     return _lib.f64x(T.as_f64_list(a, 3))
 
 
+# ---- tile order of the particles (round 3): at millions of particles the scatters run one workgroup per tile of 8^3 cells
+# with the tile's nodes in LDS (csrc/mfs_particles.hip).  The order is a permutation beside the particle arrays (particle i
+# stays particle i), computed once per position update and cached on the particle container until p.x changes.
+TILE_MIN_PARTICLES = int(os.environ.get("MFS_PARTICLE_TILE_MIN", "262144"))
+
+
+def tile_order(p, gres, bound_min, cell_size):
+    """(perm, tile_start) of p.x on the CELL grid `gres` -- int32 device tensors -- or None below TILE_MIN_PARTICLES"""
+    px = _particles(p.x, "p.x")
+    P = int(px.shape[0])
+    if P < TILE_MIN_PARTICLES:
+        return None
+    g = tuple(int(v) for v in gres)
+    geo = tuple(T.as_f64_list(bound_min, 3)) + tuple(T.as_f64_list(cell_size, 3))
+    key = (px.data_ptr(), px._version, P, g, geo)
+    c = getattr(p, "_mfs_tile_order", None)
+    if c is not None and c[0] == key:
+        return c[1], c[2]
+    lib = _lib.load()
+    nt = int(lib.mfs_particle_tiles3d(_lib.i64x(g)))
+    bufs = getattr(p, "_mfs_tile_bufs", None)
+    if bufs is None or bufs[0].numel() != P or bufs[1].numel() != nt + 1:
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=px.device)  # noqa: E731
+        bufs = (i32(P), i32(nt + 1), i32(2 * nt + P))
+        p._mfs_tile_bufs = bufs
+    perm, tstart, work = bufs
+    _lib.check(lib.mfs_particle_tile_sort3d(_lib.i64x(g), _f3(bound_min), _f3(cell_size), T.ptr(px), T.code(px), P, T.ptr(perm),
+                                            T.ptr(tstart), T.ptr(work), T.stream()), "mfs_particle_tile_sort3d")
+    p._mfs_tile_order = (key, perm, tstart)
+    return perm, tstart
+
+
+def _p2g_scatter_axis(lib, gres, g, gc, pc, axis, px, pm, pv, gm, gv, order):
+    if order is None:
+        _lib.check(lib.mfs_p2g_scatter3d(_lib.i64x(gres), _f3(g.bound_min), _f3(g.cell_size), _f3(gc.bias), axis,
+                                         T.ptr(px), T.code(px), T.ptr(pm), T.code(pm), T.ptr(pv), T.code(pv), T.ptr(pc),
+                                         T.code(pc), int(px.shape[0]), T.ptr(gm), T.ptr(gv), T.code(gm), T.stream()),
+                   "mfs_p2g_scatter3d")
+    else:
+        _lib.check(lib.mfs_p2g_scatter3d_tiled(_lib.i64x(gres), _f3(g.bound_min), _f3(g.cell_size), _f3(gc.bias), axis,
+                                               T.ptr(px), T.code(px), T.ptr(pm), T.code(pm), T.ptr(pv), T.code(pv), T.ptr(pc),
+                                               T.code(pc), int(px.shape[0]), T.ptr(order[0]), T.ptr(order[1]), T.ptr(gm),
+                                               T.ptr(gv), T.code(gm), T.stream()), "mfs_p2g_scatter3d_tiled")
+
+
 def p2g(p, g):
     """Particle -> grid (code cell 2): APIC scatter of mass and momentum to the three face arrays, then
     momentum / mass.  `p`: num_particles, x, m, v, cx, cy, cz.  `g`: resolution, bound_min, cell_size and
@@ -74,16 +121,14 @@ def p2g(p, g):
     pm = T.dev(p.m, "p.m", (px.shape[0],))
     lib = _lib.load()
     comps = ((g.x, p.cx, 0), (g.y, p.cy, 1), (g.z, p.cz, 2))
+    order = tile_order(p, gres, g.bound_min, g.cell_size)
     for gc, pc, axis in comps:
         pc = _particles(pc, "p.c" + "xyz"[axis])
         gm = T.dev(gc.m, "g.%s.m" % "xyz"[axis], T.face_shape(gres, axis))
         gv = T.dev(gc.v, "g.%s.v" % "xyz"[axis], T.face_shape(gres, axis))
         if gm.dtype != gv.dtype:
             raise TypeError("grid mass and velocity must share a dtype")
-        _lib.check(lib.mfs_p2g_scatter3d(_lib.i64x(gres), _f3(g.bound_min), _f3(g.cell_size), _f3(gc.bias), axis,
-                                         T.ptr(px), T.code(px), T.ptr(pm), T.code(pm), T.ptr(pv), T.code(pv), T.ptr(pc),
-                                         T.code(pc), int(px.shape[0]), T.ptr(gm), T.ptr(gv), T.code(gm), T.stream()),
-                   "mfs_p2g_scatter3d")
+        _p2g_scatter_axis(lib, gres, g, gc, pc, axis, px, pm, pv, gm, gv, order)
     for gc, _, axis in comps:
         _lib.check(lib.mfs_p2g_normalize3d(int(gc.m.numel()), T.ptr(gc.m), T.ptr(gc.v), T.code(gc.m), T.stream()),
                    "mfs_p2g_normalize3d")
@@ -97,14 +142,12 @@ def p2g_scatter(p, g):
     lib = _lib.load()
     if px.shape[0] == 0:
         return
+    order = tile_order(p, gres, g.bound_min, g.cell_size)
     for gc, pc, axis in ((g.x, p.cx, 0), (g.y, p.cy, 1), (g.z, p.cz, 2)):
         pc = _particles(pc, "p.c" + "xyz"[axis])
         gm = T.dev(gc.m, "g.%s.m" % "xyz"[axis], T.face_shape(gres, axis))
         gv = T.dev(gc.v, "g.%s.v" % "xyz"[axis], T.face_shape(gres, axis))
-        _lib.check(lib.mfs_p2g_scatter3d(_lib.i64x(gres), _f3(g.bound_min), _f3(g.cell_size), _f3(gc.bias), axis,
-                                         T.ptr(px), T.code(px), T.ptr(pm), T.code(pm), T.ptr(pv), T.code(pv), T.ptr(pc),
-                                         T.code(pc), int(px.shape[0]), T.ptr(gm), T.ptr(gv), T.code(gm), T.stream()),
-                   "mfs_p2g_scatter3d")
+        _p2g_scatter_axis(lib, gres, g, gc, pc, axis, px, pm, pv, gm, gv, order)
 
 
 def p2g_normalize(g):
@@ -137,6 +180,12 @@ def compute_fluid_levelset(p, ls, gdx):
     r = gdx * 0.5 * math.sqrt(3.0) * 1.02
     phi.fill_(gdx * 3)
     lib = _lib.load()
+    order = tile_order(p, gres, ls.bound_min, ls.cell_size)
+    if order is not None:
+        _lib.check(lib.mfs_fluid_levelset3d_tiled(_lib.i64x(gres), _f3(ls.bound_min), _f3(ls.cell_size), float(r), T.ptr(px),
+                                                  T.code(px), int(px.shape[0]), T.ptr(order[0]), T.ptr(order[1]), T.ptr(phi),
+                                                  T.code(phi), T.stream()), "mfs_fluid_levelset3d_tiled")
+        return
     _lib.check(lib.mfs_fluid_levelset3d(_lib.i64x(gres), _f3(ls.bound_min), _f3(ls.cell_size), float(r), T.ptr(px),
                                         T.code(px), int(px.shape[0]), T.ptr(phi), T.code(phi), T.stream()),
                "mfs_fluid_levelset3d")
@@ -149,6 +198,15 @@ def compute_fluid_volume(p, fv, pvol):
     vol = T.dev(fv.vol, "fv.vol", vres)
     vol.zero_()
     lib = _lib.load()
+    order = None
+    if all(int(v) % 2 == 1 for v in vres):       # the doubled grid of a cell grid: tiles are tiles of cells
+        gres = tuple((int(v) - 1) // 2 for v in vres)
+        order = tile_order(p, gres, fv.bound_min, 2.0 * np.asarray(T.as_f64_list(fv.cell_size, 3)))
+    if order is not None:
+        _lib.check(lib.mfs_fluid_volume3d_tiled(_lib.i64x(vres), _f3(fv.bound_min), _f3(fv.cell_size), T.ptr(px), T.code(px),
+                                                float(pvol), int(px.shape[0]), T.ptr(order[0]), T.ptr(order[1]), T.ptr(vol),
+                                                T.code(vol), T.stream()), "mfs_fluid_volume3d_tiled")
+        return
     _lib.check(lib.mfs_fluid_volume3d(_lib.i64x(vres), _f3(fv.bound_min), _f3(fv.cell_size), T.ptr(px), T.code(px),
                                       float(pvol), int(px.shape[0]), T.ptr(vol), T.code(vol), T.stream()),
                "mfs_fluid_volume3d")

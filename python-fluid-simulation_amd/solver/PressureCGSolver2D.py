@@ -107,6 +107,11 @@ class PressureCGSolver2D:
         _lib.check(int(n), "mfs_pcg2d_history")
         return buf[: int(n)].copy()
 
+    @property
+    def history_truncated(self):
+        """True if the last solve ran past the history buffer (8 191 iterations); `iterations` / `delta` stay exact"""
+        return 2 * int(self.iterations) + 1 > int(self._lib.mfs_pcg3d_history_capacity())
+
     def solve(self, vx, vy, sphi, sv, lphi, wx=None, wy=None, tol=1e-3):
         g, lib = self._g, self._lib
         if wx is None or wy is None:

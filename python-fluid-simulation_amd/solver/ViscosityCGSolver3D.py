@@ -115,6 +115,12 @@ class ViscosityCGSolver3D:
     def history(self):
         return self._engine.history()
 
+    @property
+    def history_truncated(self):
+        """True if the last solve ran past the history buffer (8 191 iterations): `history` then holds its leading entries
+        only; `iterations`, `delta`, `alpha`, `beta` are exact regardless (they come from the engine's scalar block)"""
+        return self._engine.history_truncated()
+
     def solve(self, dt, mu, rho, vx, vy, vz, sphi, sv, lphi, lvol, tol=1e-3):
         g = self._g
         scale = dt / self.cell_vol / rho                                   # :567

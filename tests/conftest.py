@@ -14,6 +14,20 @@ for p in (PKG, REPO):
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 
+# MFS_* variables set OUTSIDE the test run select non-default engine forms (MFS_FUSE_D=0, MFS_RESIDENT=0, MFS_VISC_MARCH=0 ...).
+# Tests that assert "the default form is what runs" cannot hold under them: they skip, with the reason, instead of failing
+# -- a suite run under a knob is then green or red for real reasons (round 2: 49 spurious failures under MFS_FUSE_D=0).
+_HARMLESS_KNOBS = {"MFS_COLLECTIVE_TIMEOUT_S", "MFS_P2P_TIMEOUT_MS", "MFS_BENCH_SHARED_GPU"}
+EXTERNAL_KNOBS = sorted(k for k in os.environ if k.startswith("MFS_") and k not in _HARMLESS_KNOBS)
+
+
+def require_default_engine(what="this test"):
+    """skip when an engine knob is set in the environment of the test run (tests set their own knobs with monkeypatch
+    AFTER this point; those do not count)"""
+    if EXTERNAL_KNOBS:
+        pytest.skip(f"{what} asserts the DEFAULT engine form; overridden by {', '.join(EXTERNAL_KNOBS)}")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 

@@ -10,6 +10,8 @@ initial guess (state-precision values), computes in fp64, and costs ~50 ms per 1
 """
 import numpy as np
 import pytest
+
+from conftest import require_default_engine
 import torch
 
 from mfs import scenes
@@ -22,6 +24,7 @@ H = lambda t: t.double().cpu().numpy()  # noqa: E731
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.float64, 1e-9)], ids=["f32", "f64"])
 def test_pressure_256_default_engine_vs_c_oracle(dt, tol):
+    require_default_engine("test_pressure_256_default_engine_vs_c_oracle")
     import solver.PressureCGSolver3D as P
     import solver.SolidFraction3D as S
     from mfs.pcg import PcgEngine
@@ -56,6 +59,7 @@ def test_pressure_256_default_engine_vs_c_oracle(dt, tol):
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.float64, 1e-9)], ids=["f32", "f64"])
 def test_viscosity_128_default_engine_vs_c_oracle(dt, tol):
     """BASELINE config 3: `ViscosityCGSolver3D` 128^3, buckling-like scene; the CG applies run the x-marching kernel"""
+    require_default_engine("test_viscosity_128_default_engine_vs_c_oracle")
     import solver.ViscosityCGSolver3D as V
     gres = (128, 128, 128)
     iters = 10

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, golden_names
+from conftest import golden, golden_names, require_default_engine
 from mfs.pcg import PcgEngine
 from oracle import mfs_oracle as O
 import solver.DensityCGSolver3D as D
@@ -156,6 +156,7 @@ def test_density_weights_feed_the_pressure_solve():
 def test_slab_density_solver_matches_reference(name, world, transport, tmp_path):
     """SlabDensityCGSolver3D (replicated particles, CG loop slab-decomposed over `world` processes sharing the GPU):
     history, solution, displacements and moved particles against the goldens of the reference's own solve."""
+    require_default_engine("test_slab_density_solver_matches_reference")
     from test_p2p_gpu import _run_ranks
     g = golden(name)
     extra = {}

@@ -109,3 +109,48 @@ def test_misuse_fails_loudly():
         eng.setup(good["lphi"], s.wx, s.wy, s.wz)
         z = torch.zeros(gres, dtype=torch.float64, device=DEV)
         eng.apply(z, z)
+
+
+def test_history_buffer_reports_truncation_beyond_8191_iterations():
+    """the residual-history buffer holds 16 384 doubles (8 191 iterations).  A longer run must SAY that
+    its history is truncated, and everything a caller reads besides the history -- iterations, delta, alpha, beta -- comes
+    from the engine's scalar block and stays exact.  A thin 6 x 6 x 1024 all-fluid column (CG needs ~N_z iterations there),
+    8 500 iterations with the stopping test off."""
+    from mfs import _lib
+    from mfs.pcg import PcgEngine
+    gres = (6, 6, 1024)
+    dev = "cuda:0"
+    eng = PcgEngine(gres, torch.float64, dev)
+    one = lambda *sh: torch.ones(sh, dtype=torch.float64, device=dev)  # noqa: E731
+    eng.setup(-one(*gres), one(gres[0] + 1, gres[1], gres[2]), one(gres[0], gres[1] + 1, gres[2]), one(gres[0], gres[1], gres[2] + 1))
+    g = torch.Generator(device=dev).manual_seed(4)
+    b = torch.zeros(gres, dtype=torch.float64, device=dev)
+    b[1:-1, 1:-1, 1:-1] = torch.randn((4, 4, 1022), generator=g, device=dev, dtype=torch.float64)
+    x, d, r, q = (torch.zeros(gres, dtype=torch.float64, device=dev) for _ in range(4))
+    eng.bind(b, x, d, r, q)
+    eng.begin(0.0)
+    n_short = 100
+    eng.iterate(n_short)
+    eng.finish()
+    assert not eng.history_truncated() and len(eng.history()) == 2 * n_short + 1
+    eng.begin(0.0)
+    n = 8500
+    eng.iterate(n)
+    eng.finish()
+    torch.cuda.synchronize()
+    st = eng.poll()
+    cap = int(eng.lib.mfs_pcg3d_history_capacity())
+    assert st["iterations"] == n and 2 * n + 1 > cap
+    h = eng.history()
+    assert len(h) == cap and eng.history_truncated()
+    assert np.isfinite(st["delta"]) and st["delta"] == float(eng.scalars[_lib.S_LASTRR])
+    # the true residual of the returned x agrees with the engine's delta (recursive vs true residual: a few ulps of |b|^2)
+    rr_true = float(((b - _apply(eng, x)) ** 2)[1:-1, 1:-1, 1:-1].sum())
+    assert abs(rr_true - st["delta"]) <= 1e-20 * float((b ** 2).sum()) + 10 * st["delta"]
+    assert np.all(np.isfinite(h)) and h[0] == pytest.approx(float((b ** 2).sum()), rel=1e-12)
+
+
+def _apply(eng, v):
+    out = torch.zeros_like(v)
+    eng.apply(v, out)
+    return out

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, golden
+from conftest import REPO, golden, require_default_engine
 from mfs.pcg import PcgEngine
 
 pytestmark = pytest.mark.gpu
@@ -66,6 +66,7 @@ def _run_ranks(name, world, tmp_path, dtname, solves=1, **extra_env):
     ("p3d_d_20", 5, "f64"),          # uneven slabs (4,4,3,4,3 owned planes), three ranks with two neighbours
 ])
 def test_slab_p2p_matches_single_domain(name, world, dtname, tmp_path):
+    require_default_engine("test_slab_p2p_matches_single_domain")
     g = golden(name)
     dt = torch.float64 if dtname == "f64" else torch.float32
     it0, h0, x0 = _native(g, dt)
@@ -104,6 +105,7 @@ def test_slab_p2p_matches_single_domain(name, world, dtname, tmp_path):
 def test_slab_p2p_deferred_x_update(name, world, tmp_path):
     """the slab loop with the solution update deferred into the next iteration's edge / interior launches (its default
     on production-size slabs, forced here): same history bit for bit, same solution as the undeferred loop."""
+    require_default_engine("test_slab_p2p_deferred_x_update")
     g = golden(name)
     gres = tuple(int(v) for v in g["gres"])
     out = {}
@@ -124,6 +126,7 @@ def test_slab_p2p_deferred_x_update(name, world, tmp_path):
 def test_slab_solver_class_matches_reference_outputs(name, world, tmp_path):
     """SlabPressureCGSolver3D.solve (the reference's solve signature on a rank's slab): RHS, pressure and the
     in-place velocity update against the golden outputs of the reference's own solve on the whole grid."""
+    require_default_engine("test_slab_solver_class_matches_reference_outputs")
     g = golden(name)
     gres = tuple(int(v) for v in g["gres"])
     res = _run_ranks(name, world, tmp_path, "f64", P2P_TEST_MODE="solver")
@@ -167,6 +170,7 @@ def test_lost_peer_is_reported_not_hung(mode, extra, tmp_path):
     Third case: with the fused direction update off the engine cannot take the window loop and SlabCG falls back to the
     collective loop (the configuration of round 1's stuck run, gpurun_out/suite_nofuse.log): its bounded waits must
     report the same status within MFS_COLLECTIVE_TIMEOUT_S."""
+    require_default_engine("test_lost_peer_is_reported_not_hung")
     port = _free_port()
     out = str(tmp_path / "lost")
     env = dict(os.environ, MFS_P2P_TIMEOUT_MS="400", MFS_COLLECTIVE_TIMEOUT_S="3", P2P_TEST_MODE=mode, **extra)
@@ -206,6 +210,7 @@ def _native_jacobi(g, dt):
 def test_slab_p2p_jacobi(name, world, dtname, defer, tmp_path):
     """the opt-in Jacobi loop through the window slab loop (z = r / diag as the operand of the edge and interior direction
     updates, r.r AND r.z all-reduced in the tail of the r / z update) against the single-domain Jacobi solve"""
+    require_default_engine("test_slab_p2p_jacobi")
     g = golden(name)
     dt = torch.float64 if dtname == "f64" else torch.float32
     it0, h0, x0 = _native_jacobi(g, dt)

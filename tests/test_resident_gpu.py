@@ -45,6 +45,7 @@ def _run(gres, prec, resident, iters=12, check_every=5, seed=None, switch=False,
 @pytest.mark.parametrize("gres", SHAPES)
 @pytest.mark.parametrize("prec", ["fp64", "fp32"])
 def test_resident_loop_matches_launch_per_phase_loop(gres, prec):
+    require_default_engine("test_resident_loop_matches_launch_per_phase_loop")
     # a system of a few hundred unknowns is within a few iterations of finite termination after a dozen of them, where
     # the last bit of a dot product grows tenfold per iteration (tools/res_debug.py 9 7 8: 1e-13 at iteration 6, 3e-5
     # of the -- by then 200 times smaller -- residual at 12): compare those while the comparison still means something
@@ -81,6 +82,7 @@ def test_resident_loop_against_the_oracle_history():
 def test_resident_jacobi_loop_matches_launch_per_phase_jacobi_loop(gres, prec):
     """the opt-in Jacobi iteration inside the resident launch (z = r / diag from registers, z faces exchanged, r.r and r.z in
     one exchange) against the fused two-launch Jacobi loop"""
+    require_default_engine("test_resident_jacobi_loop_matches_launch_per_phase_jacobi_loop")
     iters = 12 if int(np.prod(gres)) >= 2000 else 6
     a = _run(gres, prec, True, iters, jacobi=True)
     b = _run(gres, prec, False, iters, jacobi=True)
@@ -202,7 +204,7 @@ def test_a_launch_that_is_not_fully_resident_falls_back(monkeypatch):
 def test_resident_loop_with_the_density_operator(jacobi):
     """the density operator's asymmetric -z tap inside the resident launch (template flags ASYM x JAC), from a golden's stored
     right-hand side, against the launch-per-phase loop of the same engine settings"""
-    from conftest import golden
+    from conftest import golden, require_default_engine
     from mfs.pcg import PcgEngine
     g = golden("d3d_c_20")
     gres = tuple(int(v) for v in g["gres"])

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import golden, require_default_engine
 import notebook_sim as NSIM
 import solver.sdf3D as sdf
 
@@ -160,6 +160,7 @@ def test_two_full_steps_particles_sharded_with_the_jacobi_option(world, tmp_path
     """the sharded time step with all three solves Jacobi-preconditioned THROUGH THE WINDOW SLAB LOOPS (pressure, density:
     mfs_pcg3d_slab_*; viscosity: mfs_vcg3d_slab_*): the particles against the executed-reference goldens within the default
     path's tolerances, with fewer CG iterations than the reference's loops need on this scene"""
+    require_default_engine("test_two_full_steps_particles_sharded_with_the_jacobi_option")
     from test_p2p_gpu import _run_ranks
     g = golden("step_a_12x16x12")
     res = _run_ranks("step_a_12x16x12", world, tmp_path, "f64", P2P_TEST_MODE="timestep_sharded", P2P_TEST_JACOBI="1",

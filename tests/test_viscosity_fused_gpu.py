@@ -21,6 +21,7 @@ def _solver(gres, sc, dt, fuse):
     import solver.ViscosityCGSolver3D as V
     s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision=dt, device=DEV, check_every=8)
     s._engine.set_fuse(fuse)
+    s._engine.set_resident(False)
     s._engine.set_merged(False)        # the reference form here is the THREE-launch loop (the merged vector phases group r.r differently)
     return s
 

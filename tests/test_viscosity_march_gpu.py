@@ -6,6 +6,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import require_default_engine
 import torch
 
 from mfs import _lib, scenes
@@ -86,6 +88,7 @@ def test_march_equals_scalar_kernel_and_reference_operator(gres, dt):
 
 def test_march_is_what_runs_by_default():
     """the default engine takes the marching kernel for CG applies on an aligned grid (and says so)"""
+    require_default_engine("test_march_is_what_runs_by_default")
     from mfs.vcg import VcgEngine
     eng = VcgEngine((16, 16, 16), torch.float32, DEV)
     assert eng.apply_kernel() == "march"
@@ -100,6 +103,7 @@ def test_march_geometries_give_the_same_bits(gres, dt, monkeypatch):
     """every geometry of the marching kernel -- tiles of 256 or 512 z-vectors (512: one workgroup of eight waves per CU, what
     long rows take), ring of 4 plane slots or 3 (a second barrier per plane: fp64 rows up to Nz = 512) -- gives the bits of
     the one-cell-per-lane kernel"""
+    require_default_engine("test_march_geometries_give_the_same_bits")
     sc = scenes.viscosity_scene_3d(gres, seed=7, device=DEV, noise=0.3)
     cell_vol = float(np.prod(np.array(sc["bound_size"]) / np.array(gres)))
     scale = sc["dt"] / cell_vol / sc["rho"]
@@ -127,3 +131,116 @@ def test_march_geometries_give_the_same_bits(gres, dt, monkeypatch):
     for o, dq in zip(outs[1:], dqs[1:]):
         assert torch.equal(o, outs[0]), f"max |diff| {float((o - outs[0]).abs().max())}"
         assert abs(dq - dqs[0]) <= 1e-12 * abs(dqs[0])
+
+
+def _torch_census(gres, vol, vec):
+    """the class definition of k_vcg_classify restated on the doubled-grid volume (torch, fp of the state)"""
+    Nx, Ny, Nz = gres
+    nzv = Nz // vec
+    # compact class arrays: class p = parity bits (x odd -> 4, y odd -> 2, z odd -> 1); index = node >> 1
+    cls = {p: vol[(p >> 2) & 1::2, (p >> 1) & 1::2, p & 1::2] for p in range(1, 8)}
+
+    def win(p, dx, dy):
+        a = cls[p]
+        # vectors (x, y, zv): x in [1, Nx-2], y in [1, Ny-2], cells zv*vec .. zv*vec+vec-1 (z < Nz always inside the array)
+        blk = a[1 + dx:Nx - 1 + dx, 1 + dy:Ny - 1 + dy, :Nz]
+        return blk.reshape(Nx - 2, Ny - 2, nzv, vec)
+
+    parts = [win(p, 0, 0) for p in range(1, 8)] + [win(7, -1, 0), win(7, 0, -1), win(1, 1, 0), win(1, 0, 1), win(2, 1, 0), win(4, 0, 1)]
+    allv = torch.cat(parts, dim=-1)
+    zero = (allv == 0).all(dim=-1) & ~torch.signbit(allv).any(dim=-1)
+    bulk = vol[vol > 0].max() if bool((vol > 0).any()) else vol.new_tensor(0.0)     # k_vcg_bulk_value
+    one = (allv == bulk).all(dim=-1) & ~zero
+    return {"zero": int(zero.sum()), "one": int(one.sum()), "mixed": int((~zero & ~one).sum())}
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("gres", SHAPES + [(10, 14, 256), (6, 10, 512)], ids=lambda g: "x".join(map(str, g)))
+def test_compressed_class_access_is_bit_identical(gres, dt):
+    """round 3: the marching kernel reads the seven class arrays only for z-vectors whose samples are not uniformly 0 or 1
+    (k_vcg_classify; class bits ride in the packed mask bytes).  Same bits as dense access -- q and d.q -- on the 11 shapes
+    of this file plus two long-row geometries; the census of the classes equals the definition restated in torch; and the
+    scene really holds all three kinds wherever the grid is big enough to have bulk liquid."""
+    require_default_engine("test_compressed_class_access_is_bit_identical")
+    sc = scenes.viscosity_scene_3d(gres, seed=7, device=DEV, noise=0.3)
+    cell_vol = float(np.prod(np.array(sc["bound_size"]) / np.array(gres)))
+    scale = sc["dt"] / cell_vol / sc["rho"]
+    vol = sc["lvol"] / (cell_vol * 0.125)
+    outs, dqs = [], []
+    for comp in (True, False):
+        eng = _engine(gres, dt, 1)
+        eng.set_compress(comp)
+        eng.setup(scale, 37.0, sc["sphi"], vol)
+        d, dv = _direction(eng, sc, seed=11)
+        vecs = [eng.new_vector()[0] for _ in range(4)]
+        q = vecs[3]
+        q.fill_(3.0)
+        eng.bind(vecs[0], vecs[1], d, vecs[2], q)
+        if eng.apply_kernel() != "march":
+            pytest.skip("rows too short for the marching kernel (Nz < 2 vectors): nothing to compress")
+        eng.phase_apply()
+        eng.phase_reduce(0)
+        torch.cuda.synchronize()
+        outs.append(q.clone())
+        dqs.append(float(eng.scalars[_lib.S_DQ]))
+        if comp:
+            census = eng.class_census()
+    assert torch.equal(outs[0], outs[1]), f"compressed access changes q: max |diff| {float((outs[0] - outs[1]).abs().max())}"
+    # d.q: the same products, grouped by the cost-balanced segments of the compressed launch instead of equal ones
+    assert abs(dqs[0] - dqs[1]) <= 1e-13 * abs(dqs[1])
+    vec = 4 if dt == torch.float32 else 2
+    want = _torch_census(gres, vol.to(dt), vec)
+    assert census == want, (census, want)
+    assert sum(census.values()) == (gres[0] - 2) * (gres[1] - 2) * (gres[2] // vec)
+    assert census["zero"] > 0 and census["mixed"] > 0
+    if min(gres) >= 24 and dt == torch.float32:
+        # bulk-liquid vectors: this synthetic scene's interior volumes are products of three rounded overlaps -- uniform once
+        # rounded to fp32, a few ulps apart in fp64 (the notebook's clamped volumes are uniform in either)
+        assert census["one"] > 0, census
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_compressed_class_access_on_hostile_volumes(dt):
+    """volumes that LOOK uniform and are not: -0.0 (bit pattern differs from the constant), bulk value + 1 ulp, a single odd sample
+    at each of the neighbour positions a step reads, uniform 1.0 and uniform 0.0 fields -- compressed == dense, bit for bit"""
+    require_default_engine("test_compressed_class_access_on_hostile_volumes")
+    gres = (12, 16, 32)
+    sc = scenes.viscosity_scene_3d(gres, seed=7, device=DEV, noise=0.3)
+    cell_vol = float(np.prod(np.array(sc["bound_size"]) / np.array(gres)))
+    scale = sc["dt"] / cell_vol / sc["rho"]
+    base = torch.zeros_like(sc["lvol"])
+    cases = []
+    v = base.clone(); v[:] = 1.0; cases.append(("all one", v))
+    cases.append(("all zero", base.clone()))
+    v = base.clone(); v[8:16] = 1.0; v[::7, ::5, ::3] = -0.0; cases.append(("negative zeros", v))
+    v = base.clone(); v[:] = 1.0; v[::5, ::7, ::9] = float(np.nextafter(dt == torch.float32 and np.float32(1) or 1.0, 2)); cases.append(("one plus ulp", v))
+    g = torch.Generator(device=DEV).manual_seed(3)
+    v = base.clone(); v[:] = 1.0
+    idx = torch.randint(0, v.numel(), (200,), generator=g, device=DEV)
+    v.view(-1)[idx] = 0.37; cases.append(("isolated odd samples in bulk", v))
+    v = base.clone(); idx = torch.randint(0, v.numel(), (200,), generator=g, device=DEV)
+    v.view(-1)[idx] = 0.61; cases.append(("isolated odd samples in air", v))
+    for name, vol in cases:
+        outs = []
+        for comp in (True, False):
+            eng = _engine(gres, dt, 1)
+            eng.set_compress(comp)
+            eng.setup(scale, 37.0, sc["sphi"], vol)
+            d, dv = _direction(eng, sc, seed=11)
+            vecs = [eng.new_vector()[0] for _ in range(4)]
+            q = vecs[3]
+            q.fill_(3.0)
+            eng.bind(vecs[0], vecs[1], d, vecs[2], q)
+            eng.phase_apply()
+            torch.cuda.synchronize()
+            outs.append(q.clone())
+            if comp:
+                census = eng.class_census()
+        assert torch.equal(outs[0], outs[1]), (name, float((outs[0] - outs[1]).abs().max()))
+        # bit for bit wherever the result is not a zero (a wave whose 64 vectors are all air skips the rows and stores +0
+        # where the arithmetic 0 * d -+ 0 * d' ... would have left a zero of either sign)
+        it = torch.int32 if dt == torch.float32 else torch.int64
+        nz = outs[1] != 0
+        assert torch.equal(outs[0].view(it)[nz], outs[1].view(it)[nz]), name
+        vec = 4 if dt == torch.float32 else 2
+        assert census == _torch_census(gres, vol.to(dt), vec), name

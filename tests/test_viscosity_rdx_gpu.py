@@ -8,6 +8,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import require_default_engine
 import torch
 
 from mfs import scenes
@@ -20,6 +22,7 @@ def _solver(gres, sc, dt, merged, check_every=8):
     import solver.ViscosityCGSolver3D as V
     s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision=dt, device=DEV, check_every=check_every)
     s._engine.set_merged(merged)
+    s._engine.set_resident(False)       # (round 3: small grids default to the resident loop; this file pins the merged vector phases)
     return s
 
 
@@ -34,6 +37,7 @@ def _solve(s, sc, mu, tol):
 @pytest.mark.parametrize("gres", [(12, 12, 12), (20, 24, 36), (48, 80, 48), (33, 17, 8), (9, 11, 13), (64, 64, 64)],
                          ids=lambda g: "x".join(map(str, g)))
 def test_merged_vector_phases_match_three_launch_loop(gres, dt):
+    require_default_engine("test_merged_vector_phases_match_three_launch_loop")
     sc = scenes.viscosity_scene_3d(gres, seed=5, device=DEV, noise=0.3)
     a_s, b_s = _solver(gres, sc, dt, True), _solver(gres, sc, dt, False)
     a, b = _solve(a_s, sc, 40.0, 1e-7), _solve(b_s, sc, 40.0, 1e-7)
@@ -63,6 +67,7 @@ def test_a_launch_that_is_not_fully_resident_falls_back(monkeypatch):
     """fault injection: workgroup 5 of every merged launch never publishes its record -- what a GPU shared with other work
     does to a launch that needs all its workgroups at once.  Nothing may have been written by such a launch: the solve
     carries on in the three-launch loop and ends bit for bit where that loop ends."""
+    require_default_engine("test_a_launch_that_is_not_fully_resident_falls_back")
     gres = (20, 24, 36)
     sc = scenes.viscosity_scene_3d(gres, seed=9, device=DEV, noise=0.3)
     ref = _solve(_solver(gres, sc, "fp64", False), sc, 40.0, 1e-8)
