@@ -52,6 +52,9 @@ def parse():
                     help="N>1: how halo planes and dot products travel. p2p = xGMI stores from the solver's kernels into "
                          "HIP-IPC windows (csrc/mfs_pcg_slab.h); rccl = torch.distributed collectives per iteration; "
                          "auto = p2p if its self-test and a cross-check against rccl pass, else rccl")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="1 GPU: run the NATIVE collective slab loop (csrc/mfs_rccl.h: RCCL between the window loop's launches) on a "
+                         "1-rank communicator to price its launches and host enqueue")
     ap.add_argument("--force-p2p", action="store_true",
                     help="1 GPU: run the peer-to-peer slab loop on a 1-rank window to price its launches")
     ap.add_argument("--b2b", action="store_true", help="also time back-to-back applies (cache-warm; not the CG number)")
@@ -620,7 +623,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.force_phases or args.force_p2p:
+    if world > 1 or args.force_phases or args.force_p2p or args.force_rccl:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         from mfs.dist import pg_timeout       # bounded: a lost rank must end the run, not hang it
@@ -660,9 +663,10 @@ def main():
         eng.set_compress(False)
     if args.unfused:
         eng.set_fuse(False)
-    multi = world > 1 or args.force_phases or args.force_p2p
-    cg_rccl = mdist.SlabCG(eng, part, d, dist if multi else None, force_multi=args.force_phases or args.force_p2p)
+    multi = world > 1 or args.force_phases or args.force_p2p or args.force_rccl
+    cg_rccl = mdist.SlabCG(eng, part, d, dist if multi else None, force_multi=args.force_phases or args.force_p2p or args.force_rccl)
     cg, transport, tinfo = cg_rccl, ("rccl" if multi else "single"), {}
+    native_rccl = False
 
     def sync():
         torch.cuda.synchronize()
@@ -678,8 +682,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
+    # ---- the collective transport, native form (round 3): the window loop's launches with RCCL between them, enqueued from
+    # C.  Needs a real RCCL group (not the gloo rehearsal); trusted only after it reproduces the phase-by-phase loop's history.
+    if multi and not shared and not args.force_phases and not args.force_p2p and args.transport in ("auto", "rccl"):
+        ok, why = False, ""
+        try:
+            from mfs.rccl import RcclComm
+            comm = RcclComm(dist, dev)
+            cg_native = mdist.SlabCG(eng, part, d, dist, force_multi=True, rccl=comm)
+            V = 6
+            cg_rccl.begin(0.0)
+            cg_rccl.iterate(V)
+            h_py = eng.history()[: 2 * V + 1]
+            cg_native.begin(0.0)
+            cg_native.iterate(V)
+            cg_native.finish()
+            h_nat = eng.history()[: 2 * V + 1]
+            ok = cg_native.mode == "rccl" and len(h_nat) == len(h_py) == 2 * V + 1 and bool(max(abs(h_nat - h_py) / abs(h_py)) < 1e-9)
+            if not ok:
+                why = f"history differs from the phase-by-phase loop's (mode {cg_native.mode})"
+        except Exception as exc:      # noqa: BLE001
+            why = repr(exc)[:300]
+        ok = agree(ok)
+        tinfo["rccl_loop"] = ("native: window-loop launches, ncclSend/Recv of the edge planes on a second stream, one ncclAllReduce per "
+                              "dot product, enqueued from C (csrc/mfs_rccl.h)") if ok else ("phase-by-phase (torch.distributed); native loop not used: " + why)
+        if ok:
+            cg_rccl_phases, cg_rccl, native_rccl = cg_rccl, cg_native, True
+            if transport == "rccl":
+                cg = cg_rccl
+
     window = None
-    if multi and not args.force_phases and args.transport in ("auto", "p2p"):
+    if multi and not args.force_phases and not args.force_rccl and args.transport in ("auto", "p2p"):
         from mfs.p2p import P2PWindow
         window = P2PWindow(dist, lgres[1] * lgres[2] * esz, dev)
         tinfo["p2p_selftest"] = "ok" if window.ok else window.why
@@ -764,7 +797,7 @@ def main():
         t0_ = time.perf_counter()
         cg.iterate(args.steps)
         t_enq_ = time.perf_counter() - t0_   # host time to enqueue the steps (no sync inside)
-        if transport in ("single", "p2p"):
+        if transport in ("single", "p2p") or (transport == "rccl" and native_rccl):
             eng.finish()                   # the one solution update the fused loop still owes (inside the timed region)
         sync()
         dt_ = time.perf_counter() - t0_

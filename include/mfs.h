@@ -251,6 +251,19 @@ int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p);
  * the next poll / solve returns MFS_E_TIMEOUT.                                          */
 /* 1 if the slab loop can run on this engine (window attached, CG vectors bound and 16-byte aligned, Nz a multiple
  * of the 16-byte vector length, stencil variant 2, pressure operator); else the caller uses the collective loop */
+/* Collective transport for the slab loop (round 3): the same launches as the window loop (edge d, fused interior march,
+ * edge apply + d.q, r update + r.r) with NO in-kernel exchange -- the two edge planes travel by ncclSend / ncclRecv on the
+ * solver's second stream beside the interior launch, each dot product is ONE ncclAllReduce on the device scalar block, all
+ * enqueued from C (no host synchronisation, no Python inside a batch).  RCCL is resolved at run time from `lib_path` (the
+ * librccl the process already maps).  mfs_rccl_unique_id on rank 0 -> every rank -> mfs_rccl_create (collective); then
+ * mfs_pcg3d_attach_rccl with the rank's OWN one-rank window (mfs_p2p_create(&w, 0, 1, ...)); mfs_pcg3d_slab_begin / _iterate /
+ * _solve run the loop.  The reference is single-GPU; this is the fallback where HIP-IPC windows fail. */
+typedef struct mfs_rccl mfs_rccl;
+int mfs_rccl_unique_id_bytes(void);
+int mfs_rccl_unique_id(const char* lib_path, void* id_out);
+int mfs_rccl_create(mfs_rccl** out_host, const char* lib_path, const void* id, int rank, int world);
+int mfs_rccl_destroy(mfs_rccl* r);
+int mfs_pcg3d_attach_rccl(mfs_pcg3d* h, mfs_p2p* own_window, mfs_rccl* comm);
 int mfs_pcg3d_slab_supported(mfs_pcg3d* h);
 /* slab loop tuning: send the edge planes from a second HIP stream so that the xGMI stores overlap the interior
  * stencil launch (costs two cross-stream event hops per iteration; default: on for planes >= 1 MiB of granules) */
@@ -498,6 +511,10 @@ int mfs_p2g_scatter3d_tiled(const int64_t gres[3], const double bound_min[3], co
 int mfs_fluid_levelset3d_tiled(const int64_t gres[3], const double bound_min[3], const double cell_size[3], double radius,
                                const void* px, int px_dt, int64_t num_particles, const int32_t* perm,
                                const int32_t* tile_start, void* phi, int phi_dt, mfs_stream stream);
+/* initialize_density_kernel (solver/DensityCGSolver3D.py:8-36) on the same tile order */
+int mfs_density_splat3d_tiled(const int64_t gres[3], const double bound_min[3], const double cell_size[3], const void* px,
+                              int px_dt, const void* pm, int pm_dt, double pvol, int64_t num_particles, const int32_t* perm,
+                              const int32_t* tile_start, void* gm, void* gvol, int g_dt, mfs_stream stream);
 int mfs_fluid_volume3d_tiled(const int64_t vres[3], const double bound_min[3], const double cell_size[3], const void* px,
                              int px_dt, double pvol, int64_t num_particles, const int32_t* perm, const int32_t* tile_start,
                              void* gvol, int g_dt, mfs_stream stream);

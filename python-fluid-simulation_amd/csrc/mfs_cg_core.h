@@ -62,8 +62,22 @@ template <typename T, int VEC>
 __device__ __forceinline__ Vec<T, VEC> ldv(const T* p) { return *reinterpret_cast<const Vec<T, VEC>*>(p); }
 
 // ---------------------------------------------------------- vector phases ---
+// LIVE CHUNKS (round 3, viscosity): a flat CG vector cut into chunks of 2^shift vectors; `list[0 .. *count)` names the
+// chunks that hold at least one unknown that is not identically zero for the whole solve (its operator row is empty and
+// its right-hand side 0: a face in the air).  The vector phases then sweep only those -- r, d and q ARE zero elsewhere and
+// x does not change there -- which is most of the work in a liquid scene.  list == nullptr: every chunk (the default).
+struct LiveMap {
+  const int* list;
+  const int* count;
+  int shift;
+};
+__device__ __forceinline__ int64_t live_nv(const LiveMap& lm, int64_t nv) { return lm.list ? ((int64_t)*lm.count << lm.shift) : nv; }
+__device__ __forceinline__ int64_t live_vec(const LiveMap& lm, int64_t k) {
+  return lm.list ? (((int64_t)lm.list[k >> lm.shift] << lm.shift) | (k & ((1 << lm.shift) - 1))) : k;
+}
+
 template <typename T, int VEC, typename F>
-__device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = false, bool blocked = false) {
+__device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = false, bool blocked = false, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   // f(i, vec): process elements [i, i+VEC) (vec) or the single element i (tail).
   // reverse: sweep from the end of the array to its start -- consecutive CG phases
   // alternate direction so each one starts on the bytes the previous one touched
@@ -78,8 +92,16 @@ __device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = fa
     for (int64_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) f(k * VEC, true);
   } else {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride)
-      f((reverse ? nv - 1 - k : k) * VEC, true);
+    if (lm.list) {      // live chunks only (the last chunk of the vector may reach past its end)
+      const int64_t nvl = live_nv(lm, nv);
+      for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nvl; k += stride) {
+        const int64_t kr = live_vec(lm, reverse ? nvl - 1 - k : k);
+        if (kr < nv) f(kr * VEC, true);
+      }
+    } else {
+      for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += stride)
+        f((reverse ? nv - 1 - k : k) * VEC, true);
+    }
   }
   // scalar tail (n % VEC elements) handled by the first threads of block 0
   const int64_t tail = n - nv * VEC;
@@ -255,7 +277,8 @@ __device__ __forceinline__ void slab_fail(double* scal, int code) {
 
 // what the LAST block of k_update_xr does after the r.r partials are complete
 struct XrTail {
-  int kind;                 // 0 nothing; 1 bookkeeping (one GPU); 2 all-reduce over the windows, then bookkeeping (slab loop)
+  int kind;                 // 0 nothing; 1 bookkeeping (one GPU); 2 all-reduce over the windows, then bookkeeping (slab loop);
+                            // 3 the rank's total into scalars[RR] only (collective transport: all-reduce + k_cg_book follow)
   double* hist;
   int64_t hist_cap;
   unsigned* ticket;
@@ -272,16 +295,18 @@ template <typename T, int VEC, bool NTX, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const T* __restrict__ q, int64_t n,
             double* __restrict__ scal, double* __restrict__ partial, int rev, int par,
-            const double* __restrict__ part_dq, int npart, XrTail tail, P2pDev pd) {
+            const double* __restrict__ part_dq, int npart, XrTail tail, P2pDev pd, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   // Everything this block needs first is requested in ONE batch -- the done flag, the delta ring, the d.q partials and
   // the first vector of every lane -- and only then waited for: on a small grid the kernel is a chain of memory round
   // trips, and flag -> partials -> vectors in sequence were three of them.  (Loads past a raised flag are harmless.)
   const double dn = scal[S_DONE];
   const double delta = scal[S_RING + par];
-  const int64_t nv = n / VEC;
+  const int64_t nv_all = n / VEC;
+  const int64_t nv = live_nv(lm, nv_all);                 // vectors swept: all of them, or those of the live chunks
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t k0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool rv_ = rev != 0;
+  auto vec_at = [&](int64_t k) { return live_vec(lm, rv_ ? nv - 1 - k : k); };      // (may reach past the end in the last live chunk)
   vec_t<T, VEC> xv = {}, dv = {}, rv = {}, qv = {};
   auto fetch = [&](int64_t i) {
     if (MODE != 1) {
@@ -294,7 +319,7 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
       qv = (MODE == 1 && NTX) ? vload_nt<T, VEC>(q + i) : vload<T, VEC>(q + i);
     }
   };
-  if (k0 < nv) fetch((rv_ ? nv - 1 - k0 : k0) * VEC);
+  if (k0 < nv && vec_at(k0) < nv_all) fetch(vec_at(k0) * VEC);
   // d.q: folded reduction of the apply's partials (npart > 0) or the all-reduced scalar
   const double dq = npart > 0 ? block_total_of(part_dq, npart) : scal[S_DQ];
   if (dn != 0.0) return;
@@ -303,7 +328,9 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
   double acc = 0.0;
   // sweep direction: see for_each_vec (same order of the vectors per lane, so the r.r partials group identically)
   for (int64_t k = k0; k < nv; k += stride) {
-    const int64_t i = (rv_ ? nv - 1 - k : k) * VEC;
+    const int64_t kr = vec_at(k);
+    if (kr >= nv_all) continue;
+    const int64_t i = kr * VEC;
     if (k != k0) fetch(i);
     if (MODE != 1) {
 #pragma unroll
@@ -320,9 +347,9 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
     }
   }
   {   // scalar tail (n % VEC elements): the first threads of block 0, after their vectors
-    const int64_t rest = n - nv * VEC;
+    const int64_t rest = n - nv_all * VEC;
     if (blockIdx.x == 0 && (int64_t)threadIdx.x < rest) {
-      const int64_t i = nv * VEC + threadIdx.x;
+      const int64_t i = nv_all * VEC + threadIdx.x;
       if (MODE != 1) x[i] = (T)((double)x[i] + alpha * (double)d[i]);
       if (MODE != 2) {
         const T rn = (T)((double)r[i] - alpha * (double)q[i]);
@@ -346,6 +373,10 @@ k_update_xr(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, const
       rr = slab_allreduce_wave(pd, tail.ring, tail.tag, rr, &ok);
       if (!ok) { if (threadIdx.x == 0) slab_fail(scal, 1); return; }
     }
+    if (tail.kind == 3) {      // collective transport: this rank's r.r into the scalar block; an all-reduce and k_cg_book follow
+      if (threadIdx.x == 0) scal[S_RR] = rr;
+      return;
+    }
     if (threadIdx.x == 0) cg_book(scal, tail.hist, tail.hist_cap, par, dq, rr);
   }
 }
@@ -358,7 +389,7 @@ template <typename T, int VEC, bool XUPD = false, bool NTX = false>
 __global__ void __launch_bounds__(kBlock)
 k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __restrict__ scal,
            double* __restrict__ hist, int64_t hist_cap, int rev, int par, const double* __restrict__ part_rr,
-           int npart, T* __restrict__ x = nullptr, int nt_r = 0, double own_mark = 1.0) {
+           int npart, T* __restrict__ x = nullptr, int nt_r = 0, double own_mark = 1.0, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   // `done` is raised by THIS kernel's bookkeeping thread on the converging iteration, and with XUPD the other blocks
   // still owe the final x += alpha d: a block that starts after that store must not mistake it for an older one.
   // The marker written here is unique to the launch (own_mark = -(iteration + 1); every other writer stores +1), a
@@ -419,7 +450,7 @@ k_update_d(T* __restrict__ d, const T* __restrict__ r, int64_t n, double* __rest
       if (conv) return;
       d[i] = (T)((double)r[i] + beta * (double)d[i]);
     }
-  }, rev == 1, rev == 2);
+  }, rev == 1, rev == 2, lm);
 }
 
 // ---- small problems: the two vector phases of an iteration in ONE launch (k_update_rdx) -----------------------------
@@ -650,7 +681,7 @@ static __global__ void __launch_bounds__(kBlock)
 k_cg_book(double* __restrict__ scal, double* __restrict__ hist, int64_t hist_cap, int par,
           const double* __restrict__ part_rr, int npart) {
   if (scal[S_DONE] != 0.0) return;
-  const double rr = block_total_of(part_rr, npart);
+  const double rr = npart > 0 ? block_total_of(part_rr, npart) : scal[S_RR];      // (npart == 0: the all-reduced scalar)
   if (threadIdx.x == 0) cg_book(scal, hist, hist_cap, par, scal[S_DQ], rr);
 }
 
@@ -966,6 +997,7 @@ struct CgCore {
   unsigned long long rdx_timeout_ticks = 25000000ull;   // MFS_RDX_TIMEOUT_MS (wall clock, 100 MHz)
   int rdx_drop_wg = -1;                                 // MFS_RDX_TEST_DROP_WG: fault injection, tests only
   int nt_q = -1, nt_rd = -1;                            // MFS_NT_Q, MFS_NT_RD (A/B: -1 auto by size)
+  LiveMap live{nullptr, nullptr, 0};                    // live chunks of the bound vectors (viscosity, single domain); null: all
 };
 
 static inline size_t core_ws_bytes() {
@@ -1046,7 +1078,7 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
 #define MFS_XR(TT, VV, NN, MM) \
   hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x + off, (const TT*)dsrc + off, \
                      (TT*)c.r + off, (const TT*)c.q + off, cnt, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), \
-                     c.part_dq, fold ? c.n_part_dq : 0, tl, pdv)
+                     c.part_dq, fold ? c.n_part_dq : 0, tl, pdv, (off == 0 && cnt == c.n) ? c.live : LiveMap{nullptr, nullptr, 0})
 #define MFS_XR_MODE(MM)                                                                                              \
   if (c.dt == MFS_F32) {                                                                                             \
     if (!vec) MFS_XR(float, 1, false, MM); else if (ntx) MFS_XR(float, 4, true, MM); else MFS_XR(float, 4, false, MM); \
@@ -1099,7 +1131,7 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
 #define MFS_UD(TT, VV, NN) \
     hipLaunchKernelGGL((k_update_d<TT, VV, true, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
                        c.hist, kHistCap, rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r, \
-                       -(double)(c.iter_enq + 1))
+                       -(double)(c.iter_enq + 1), c.live)
     const int rev_d = c.rev_d;
     // ... and so is r here (same-engine A/B: viscosity 256^3 632.8 -> 596.6 us/iteration, 192^3 250.0 -> 243.6)
     const int nt_r_knob = c.nt_rd;

@@ -79,6 +79,57 @@ k_density_splat(DGrid g, D3 bmin, D3 cs, const void* px, int pxdt, const void* p
       }
 }
 
+// the same scatter, one workgroup per tile of 8^3 cells of a tile-sorted particle order (mfs_particle_tile_sort3d,
+// csrc/mfs_particles.hip): the tile's cell centres [c0 - 1, c0 + 8] per axis staged in LDS, one global atomic per touched
+// cell and tile; contributions outside the staged box (a particle that moved since the sort) take the global atomic
+__global__ void __launch_bounds__(256)
+k_density_splat_tiled(DGrid g, D3 bmin, D3 cs, int t1, int t2, const void* px, int pxdt, const void* pm, int pmdt, double pvol,
+                      const int* __restrict__ perm, const int* __restrict__ tstart, void* gm, void* gvol, int gdt) {
+  constexpr int TB = 8, E = TB + 2;
+  __shared__ double lm[E * E * E], lv[E * E * E];
+  const int tile = blockIdx.x;
+  const int a = tstart[tile], b = tstart[tile + 1];
+  if (a == b) return;
+  const int tz = tile % t2, ty = (tile / t2) % t1, tx = tile / (t2 * t1);
+  const int o[3] = {tx * TB - 1, ty * TB - 1, tz * TB - 1};
+  for (int l = threadIdx.x; l < E * E * E; l += 256) { lm[l] = 0.0; lv[l] = 0.0; }
+  __syncthreads();
+  for (int i = a + threadIdx.x; i < b; i += 256) {
+    const int64_t p = perm[i];
+    const double m = ldx(pm, pmdt, p);
+    long long gi[3];
+    double w[3];
+    particle_cell(px, pxdt, p, bmin, cs, D3{{0.5, 0.5, 0.5}}, gi, w);
+    for (int ix = 0; ix < 2; ++ix)
+      for (int iy = 0; iy < 2; ++iy)
+        for (int iz = 0; iz < 2; ++iz) {
+          const int cx = (int)max(0LL, min((long long)g.Nx - 1, gi[0] + ix));
+          const int cy = (int)max(0LL, min((long long)g.Ny - 1, gi[1] + iy));
+          const int cz = (int)max(0LL, min((long long)g.Nz - 1, gi[2] + iz));
+          const double weight = corner_weight(ix, w[0]) * corner_weight(iy, w[1]) * corner_weight(iz, w[2]);
+          const int lx = cx - o[0], ly = cy - o[1], lz = cz - o[2];
+          if ((unsigned)lx < (unsigned)E && (unsigned)ly < (unsigned)E && (unsigned)lz < (unsigned)E) {
+            const int l = (lx * E + ly) * E + lz;
+            atomicAdd(&lm[l], weight * m);
+            atomicAdd(&lv[l], weight * pvol);
+          } else {
+            const int64_t c = g.fx(cx, cy, cz);
+            atomic_addx(gm, gdt, c, weight * m);
+            atomic_addx(gvol, gdt, c, weight * pvol);
+          }
+        }
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < E * E * E; l += 256) {
+    const double vm = lm[l], vv = lv[l];
+    if (vm == 0.0 && vv == 0.0) continue;
+    const int lz = l % E, ly = (l / E) % E, lx = l / (E * E);
+    const int64_t c = g.fx(o[0] + lx, o[1] + ly, o[2] + lz);
+    atomic_addx(gm, gdt, c, vm);
+    atomic_addx(gvol, gdt, c, vv);
+  }
+}
+
 __device__ __forceinline__ double nonsolid_frac(const DGrid& g, const void* wx, const void* wy, const void* wz, int wdt,
                                                 int x, int y, int z) {
   return (ldx(wx, wdt, g.fx(x, y, z)) + ldx(wx, wdt, g.fx(x + 1, y, z)) + ldx(wy, wdt, g.fy(x, y, z)) +
@@ -221,6 +272,23 @@ int mfs_density_splat3d(const int64_t gres[3], const double bound_min[3], const 
   hipLaunchKernelGGL(k_density_splat, dim3(cdiv(num_particles, 256)), dim3(256), 0, (hipStream_t)stream, g,
                      D3{{bound_min[0], bound_min[1], bound_min[2]}}, D3{{cell_size[0], cell_size[1], cell_size[2]}}, px,
                      px_dt, pm, pm_dt, pvol, num_particles, gm, gvol, g_dt);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
+}
+
+int mfs_density_splat3d_tiled(const int64_t gres[3], const double bound_min[3], const double cell_size[3], const void* px,
+                              int px_dt, const void* pm, int pm_dt, double pvol, int64_t num_particles, const int32_t* perm,
+                              const int32_t* tile_start, void* gm, void* gvol, int g_dt, mfs_stream stream) {
+  if (int e = check_g(gres)) return e;
+  MFS_REQUIRE(bound_min && cell_size && gm && gvol && perm && tile_start, "null argument");
+  MFS_REQUIRE(num_particles >= 0 && (num_particles == 0 || (px && pm)), "particle arrays");
+  MFS_REQUIRE(dtype_ok(px_dt) && dtype_ok(pm_dt) && dtype_ok(g_dt), "dtype");
+  if (num_particles == 0) return MFS_OK;
+  DGrid g{(int)gres[0], (int)gres[1], (int)gres[2]};
+  const int t0 = (int)((gres[0] + 7) / 8), t1 = (int)((gres[1] + 7) / 8), t2 = (int)((gres[2] + 7) / 8);
+  hipLaunchKernelGGL(k_density_splat_tiled, dim3(t0 * t1 * t2), dim3(256), 0, (hipStream_t)stream, g,
+                     D3{{bound_min[0], bound_min[1], bound_min[2]}}, D3{{cell_size[0], cell_size[1], cell_size[2]}}, t1, t2, px,
+                     px_dt, pm, pm_dt, pvol, perm, tile_start, gm, gvol, g_dt);
   MFS_LAUNCH_CHECK();
   return MFS_OK;
 }

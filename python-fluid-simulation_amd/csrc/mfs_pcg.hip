@@ -15,6 +15,7 @@
 #include "mfs_cg_core.h"
 #include "mfs_pcg_apply.h"
 #include "mfs_pcg_slab.h"
+#include "mfs_rccl.h"
 #include "mfs_pcg_resident.h"
 
 namespace mfs {
@@ -114,6 +115,8 @@ struct mfs_pcg3d {
   // the xGMI stores (whose completion the producing kernel has to wait for) overlap the interior stencil launch
   hipStream_t aux;
   hipEvent_t ev_main, ev_aux;
+  mfs_rccl* rccl;              // collective transport of the slab loop (mfs_pcg3d_attach_rccl): the attached window is then this
+                               // rank's OWN 1-rank window, halo planes and dot products travel through RCCL between the launches
   int use_aux;
 };
 
@@ -323,6 +326,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->is_setup = false;
   h->p2p = nullptr;
   h->aux = nullptr; h->ev_main = nullptr; h->ev_aux = nullptr;
+  h->rccl = nullptr;
   h->use_aux = env_int("MFS_SLAB_AUX_STREAM", -1);   // -1: decided at attach time from the plane size
   if (hipMemsetAsync(workspace, 0, mfs_pcg3d_workspace_bytes(gres, dt), (hipStream_t)stream) != hipSuccess) {
     set_error("hipMemsetAsync(workspace) failed");
@@ -967,7 +971,9 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
   const bool xdef = xdef_ok(h) && L - 2 > 2;
   // 1. edge planes of d_j: local + into the neighbours' windows -- on the second stream, behind everything
   //    the main stream has done so far (beta, r of the previous iteration)
-  const bool aux = h->use_aux && h->aux && e.np > 0 && L - 2 > 2;
+  mfs_rccl* const rc = h->rccl;      // collective transport: RCCL moves the planes and sums the dot products between the launches
+  if (rc) MFS_REQUIRE(!jac, "the collective slab loop has no Jacobi form");
+  const bool aux = (rc != nullptr || h->use_aux) && h->aux && e.np > 0 && L - 2 > 2;
   hipStream_t se = aux ? h->aux : st;
   if (aux) {
     MFS_HIP_TRY(hipEventRecord(h->ev_main, st));
@@ -983,6 +989,8 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
                          d_cur, plane_elems, e, h->c.scal, p->dev, par, halo_tag, xdef ? (T*)h->c.x : (T*)nullptr);
     MFS_LAUNCH_CHECK();
   }
+  if (rc && e.np > 0)      // ... and to / from the neighbours: one send / recv group behind the edge kernel
+    if ((e_ = rccl_halo(rc, (char*)d_cur, (size_t)plane_elems * sizeof(T), L, se))) return e_;
   if (aux) MFS_HIP_TRY(hipEventRecord(h->ev_aux, h->aux));
   // 2. planes that touch no ghost, while the edge planes travel
   int n_part = 0;
@@ -1009,6 +1017,7 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
                        (int)(ep_dq & (kArRing - 1)), slab_ar_tag(p, ep_dq));
     MFS_LAUNCH_CHECK();
     n_part += grid;
+    if (rc && (e_ = rccl_sum(rc, h->c.scal + S_DQ, 1, st))) return e_;      // the edge launch left THIS rank's d.q there
   }
   h->c.n_part_dq = n_part;
   if (jac) {
@@ -1033,6 +1042,16 @@ static int slab_iteration(mfs_pcg3d* h, hipStream_t st) {
     return MFS_OK;
   }
   // 4. x, r update (r only when the x update is deferred); its last block: r.r over all ranks + bookkeeping
+  if (rc) {      // r.r: the rank's total into the scalar block, ONE all-reduce, then the one-block bookkeeping
+    if (xdef) h->x_owed = true;
+    XrTail tl{3, h->c.hist, kHistCap, nullptr, 0, 0};
+    if ((e_ = core_update_xr(h->c, false, st, xdef ? 1 : 0, d_cur, plane_elems, plane_elems * (L - 2), &tl, &p->dev))) return e_;
+    if ((e_ = rccl_sum(rc, h->c.scal + S_RR, 1, st))) return e_;
+    hipLaunchKernelGGL(k_cg_book, dim3(1), dim3(kBlock), 0, st, h->c.scal, h->c.hist, kHistCap, par, h->c.part_rr, 0);
+    MFS_LAUNCH_CHECK();
+    ++h->c.iter_enq;
+    return MFS_OK;
+  }
   if (xdef) {
     h->x_owed = true;
     XrTail tl{2, h->c.hist, kHistCap, nullptr, (int)((2 * j + 2) & (kArRing - 1)), slab_ar_tag(p, 2 * j + 2)};
@@ -1060,6 +1079,63 @@ int mfs_pcg3d_attach_p2p(mfs_pcg3d* h, mfs_p2p* p) {
     if (h->use_aux < 0) h->use_aux = (p->world > 1 && 2 * p->plane_bytes >= (1u << 20)) ? 1 : 0;
     return mfs_pcg3d_slab_set_aux(h, h->use_aux);
   }
+  return MFS_OK;
+}
+
+// collective transport for the slab loop: `p` must be this rank's OWN one-rank window (mfs_p2p_create(rank 0, world 1)),
+// `rc` the communicator over the slab ranks.  The loop then runs the window loop's launches with no in-kernel exchange:
+// edge planes by ncclSend / ncclRecv on the second stream beside the interior launch, each dot product one ncclAllReduce.
+int mfs_pcg3d_attach_rccl(mfs_pcg3d* h, mfs_p2p* p, mfs_rccl* rc) {
+  MFS_REQUIRE(h, "null handle");
+  if (!rc) { h->rccl = nullptr; return mfs_pcg3d_attach_p2p(h, nullptr); }
+  MFS_REQUIRE(p && p->connected && p->world == 1, "the collective loop takes this rank's own one-rank window");
+  MFS_REQUIRE(rc->comm, "communicator not initialised");
+  if (int e = mfs_pcg3d_attach_p2p(h, p)) return e;
+  h->rccl = rc;
+  h->use_aux = 1;
+  if (!h->aux) {
+    MFS_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    MFS_HIP_TRY(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    MFS_HIP_TRY(hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming));
+  }
+  return MFS_OK;
+}
+
+int mfs_rccl_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+// rank 0 calls this and hands the bytes to every rank (torch.distributed broadcast); `lib_path`: the librccl the process carries
+int mfs_rccl_unique_id(const char* lib_path, void* id_out) {
+  MFS_REQUIRE(lib_path && id_out, "null argument");
+  mfs_rccl tmp;
+  if (int e = rccl_load(&tmp, lib_path)) return e;
+  ncclUniqueId id;
+  MFS_RCCL_TRY(&tmp, tmp.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return MFS_OK;
+}
+
+// COLLECTIVE over the `world` ranks: every rank calls with the same id (the calling thread's current device is the rank's GPU)
+int mfs_rccl_create(mfs_rccl** out, const char* lib_path, const void* id, int rank, int world) {
+  MFS_REQUIRE(out && lib_path && id && world >= 1 && rank >= 0 && rank < world, "arguments");
+  mfs_rccl* r = new mfs_rccl();
+  if (int e = rccl_load(r, lib_path)) { delete r; return e; }
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  r->rank = rank; r->world = world;
+  const ncclResult_t rc = r->CommInitRank(&r->comm, world, uid, rank);
+  if (rc != ncclSuccess) {
+    set_error("ncclCommInitRank failed: %s", r->GetErrorString(rc));
+    delete r;
+    return MFS_E_HIP;
+  }
+  *out = r;
+  return MFS_OK;
+}
+
+int mfs_rccl_destroy(mfs_rccl* r) {
+  if (!r) return MFS_OK;
+  if (r->comm) (void)r->CommDestroy(r->comm);
+  delete r;
   return MFS_OK;
 }
 
@@ -1091,6 +1167,7 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;
   if (int e = apply_dispatch(h, h->c.x, h->c.q, 1, h->Nx - 1, h->c.part_dq, 0, st, &grid)) return e;  // q = A x (:201)
+  MFS_REQUIRE(!(h->rccl && h->jacobi), "the collective slab loop has no Jacobi form (mfs_pcg3d_set_jacobi(0) first)");
   if (h->jacobi) {     // r = b - q, d = z = r / diag, both dot products over all ranks (episodes 0 and 1), delta0 = r.z
     const int g2 = std::max(1, (int)std::min<int64_t>(h->c.grid_vec, (h->n + kBlock - 1) / kBlock));
     if (h->dt == MFS_F32)
@@ -1112,6 +1189,7 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   hipLaunchKernelGGL(k_slab_allreduce_rr, dim3(1), dim3(kBlock), 0, st, h->c.part_rr, h->c.n_part_rr, h->c.scal,
                      h->p2p->dev, 0, slab_ar_tag(h->p2p, 0));
   MFS_LAUNCH_CHECK();
+  if (h->rccl) { if (int e = rccl_sum(h->rccl, h->c.scal + S_RR, 1, st)) return e; }      // (the window is this rank's own)
   return core_begin_finish(h->c, st);
 }
 

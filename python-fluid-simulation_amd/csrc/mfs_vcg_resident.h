@@ -35,7 +35,7 @@ constexpr int kVResMaxW = 256;
 constexpr int kVResRing = 4;
 constexpr int64_t kVResMaxDofs = 1 << 20;            // grids beyond this never qualify (mirror sizing)
 constexpr size_t kVResLdsMax = 150 * 1024;
-constexpr int kVResRecStride = 16;                    // u64 words between two workgroups' records (128 bytes)
+constexpr int kVResRecStride = 64;                    // u64 words between two workgroups' records (512 bytes: one per line pair, as in the pressure loop)
 constexpr int kVResHB = 4;                            // halo requests a thread keeps in flight
 constexpr int kVResHK = 8;                            // halo elements per thread, at most (plans with more do not qualify)
 
@@ -101,27 +101,40 @@ __device__ __forceinline__ double vres_allreduce_end(u64* ar, int W, unsigned ta
   __shared__ int s_ok;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (wave == 0) {
-    double c[kVResMaxW / kWave];
+    constexpr int M = kVResMaxW / kWave;
+    static_assert(M == 4, "the batched poll below names four request registers");
+    double c[M];
     bool good = true;
+    // all of this lane's records are requested at once, ONE wait per round (four sequential polls were four L2 round
+    // trips: most of the reduction's latency); rounds repeat, for the records still missing, until every lane has its four
+    vres_u64x2 w[M];
+    bool got[M];
 #pragma unroll
-    for (int m = 0; m < kVResMaxW / kWave; ++m) {
-      c[m] = 0.0;
-      const int wg = m * kWave + lane;
-      if (wg < W) {
-        const u64* g = ar + ((size_t)(tag % kVResRing) * kVResMaxW + wg) * kVResRecStride;
-        vres_u64x2 w = vres_load2(g);
-        bool got = (w[0] >> 32) == tag && (w[1] >> 32) == tag;
-        for (int spin = 0; spin < 64 && !got; ++spin) { w = vres_load2(g); got = (w[0] >> 32) == tag && (w[1] >> 32) == tag; }
-        if (!got && good) {
-          const u64 t0 = wall_clock64();
-          for (;;) {
-            __builtin_amdgcn_s_sleep(1);
-            w = vres_load2(g);
-            if ((w[0] >> 32) == tag && (w[1] >> 32) == tag) break;
-            if (wall_clock64() - t0 > timeout_ticks) { good = false; break; }
-          }
+    for (int m = 0; m < M; ++m) { w[m][0] = 0; w[m][1] = 0; got[m] = m * kWave + lane >= W; c[m] = 0.0; }
+    u64 t0 = 0;
+    for (int round = 0;; ++round) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (!got[m]) {
+          const u64* g = ar + ((size_t)(tag % kVResRing) * kVResMaxW + m * kWave + lane) * kVResRecStride;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[m]) : "v"(g) : "memory");
         }
-        c[m] = __longlong_as_double((long long)((w[1] << 32) | (w[0] & 0xffffffffull)));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
+      bool all = true;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (!got[m] && (w[m][0] >> 32) == tag && (w[m][1] >> 32) == tag) {
+          got[m] = true;
+          c[m] = __longlong_as_double((long long)((w[m][1] << 32) | (w[m][0] & 0xffffffffull)));
+        }
+        all = all && got[m];
+      }
+      if (__all(all)) break;
+      if (round == 64) t0 = wall_clock64();              // the first rounds read no clock (itself a memory-latency operation)
+      if (round > 64) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_ballot_w64(wall_clock64() - t0 > timeout_ticks) != 0) { good = all; break; }      // (wave-uniform exit)
       }
     }
     good = __all(good);

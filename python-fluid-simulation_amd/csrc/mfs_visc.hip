@@ -923,6 +923,10 @@ struct mfs_vcg3d {
   u64 res_timeout_ticks, res_first_timeout_ticks;      // read once at creation
   int res_drop_wg;                                     // MFS_VRES_TEST_DROP_WG: fault injection, tests only
   int res_creg;                                        // MFS_VRES_CREG (default 1): volume samples in registers where they fit
+  int sparse_vec;       // 1 (default; MFS_VISC_SPARSE): the vector phases of a single-domain solve sweep live chunks only
+  int64_t sparse_min;   // ... from this many unknowns on (smaller grids run the resident / merged loops)
+  int* live_ws;         // flags | list | count
+  bool classes_ready;   // the compressed class access' classes / tile flags / balanced cut match the current set-up
   int compress;    // 1 (default; MFS_VISC_COMPRESS): the march reads the class arrays only for MIXED vectors (k_vcg_classify)
   int march_nt;    // MFS_VISC_MARCH_NT: nontemporal class loads / q stores (-1 auto by size), read at creation
   int fuse;        // 1: mfs_vcg3d_iterate / solve fold the direction and x updates into the march (2 launches per iteration); default 0
@@ -1068,6 +1072,141 @@ static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* 
   return vcg_march_launch_blk<T, VEC, WAVES, NT, FUSE, 256, 4, COMP>(h, vv, ob, partial, done, st, nparts, fz);
 }
 
+// ---- live chunks of the flat CG vectors (mfs_cg_core.h LiveMap): a face is DEAD when its operator row is empty -- an
+// array-boundary face, a solid face, or all seven volume samples of its row 0 -- and r = d = 0 there at the start of the
+// loop (b - A x0 = 0): then q, r and d stay exactly 0 and x never changes.  A chunk of 1024 unknowns is live when any of
+// its faces is not dead.  Built once per solve (single-domain loops), behind the initial residual.
+constexpr int kLiveChunk = 1024;
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_vcg_live_flags(Compact c, const T* __restrict__ r, const T* __restrict__ d, int64_t n, int64_t o1, int64_t o2, int* __restrict__ flags) {
+  const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = iv * VEC;
+  bool live = false;
+  if (i0 < n) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int64_t i = i0 + j;
+      if (i >= n) break;
+      if (r[i] != (T)0 || d[i] != (T)0) { live = true; continue; }
+      const int comp = i >= o2 ? 2 : (i >= o1 ? 1 : 0);
+      const int64_t f = i - (comp == 2 ? o2 : (comp == 1 ? o1 : 0));
+      const int s1 = c.N[1] + (comp == 1), s2 = c.N[2] + (comp == 2), s0 = c.N[0] + (comp == 0);
+      const int z = (int)(f % s2), y = (int)((f / s2) % s1), x = (int)(f / ((int64_t)s2 * s1));
+      if (x < 1 || x > s0 - 2 || y < 1 || y > s1 - 2 || z < 1 || z > s2 - 2) continue;          // array boundary: never computed
+      if (!((c.msk[c.idx(x, y, z)] >> comp) & 1)) continue;                                       // solid face: q = 0
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int ax = kD0[comp][0] + kVolOff[k][0], ay = kD0[comp][1] + kVolOff[k][1], az = kD0[comp][2] + kVolOff[k][2];
+        const int p = ((ax & 1) << 2) | ((ay & 1) << 1) | (az & 1);
+        if (((const T*)c.vol[p])[c.idx(x + fdiv2(ax), y + fdiv2(ay), z + fdiv2(az))] != (T)0) live = true;
+      }
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(live) != 0 && (threadIdx.x & 63) == 0) {
+    // a wave's 64 vectors span at most two chunks
+    const int64_t c0 = i0 / kLiveChunk, c1 = min(n - 1, i0 + 64 * VEC - 1) / kLiveChunk;
+    flags[c0] = 1;
+    if (c1 != c0) flags[c1] = 1;
+  }
+}
+
+// flags -> list of live chunk indices + their count (ONE block)
+__global__ void __launch_bounds__(1024)
+k_vcg_live_list(const int* __restrict__ flags, int nchunks, int* __restrict__ list, int* __restrict__ count) {
+  const int t = threadIdx.x;
+  const int per = (nchunks + 1023) / 1024, i0 = min(nchunks, t * per), i1 = min(nchunks, i0 + per);
+  int sum = 0;
+  for (int i = i0; i < i1; ++i) sum += flags[i] != 0;
+  __shared__ int s_pre[1024];
+  s_pre[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? s_pre[t - o] : 0;
+    __syncthreads();
+    s_pre[t] += v;
+    __syncthreads();
+  }
+  int run = s_pre[t] - sum;
+  for (int i = i0; i < i1; ++i)
+    if (flags[i] != 0) list[run++] = i;
+  if (t == 1023) *count = s_pre[1023];
+}
+
+static size_t live_ws_bytes(int64_t n) { return align_up((size_t)(2 * ((n + kLiveChunk - 1) / kLiveChunk) + 64) * sizeof(int), 4096); }
+
+// (a wave marks the chunks of ALL its 64 vectors live when any of them is: conservative, never wrong)
+static int vcg_build_live(mfs_vcg3d* h, hipStream_t st) {
+  h->c.live = LiveMap{nullptr, nullptr, 0};
+  if (!h->sparse_vec || !core_vec_ok(h->c) || h->n < h->sparse_min) return MFS_OK;
+  const int vec = h->dt == MFS_F32 ? 4 : 2;
+  const int nchunks = (int)((h->n + kLiveChunk - 1) / kLiveChunk);
+  int* flags = h->live_ws;
+  int* list = flags + nchunks;
+  int* count = list + nchunks;
+  MFS_HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nchunks * sizeof(int), st));
+  const int64_t nvec = (h->n + vec - 1) / vec;
+  if (h->dt == MFS_F32)
+    hipLaunchKernelGGL((k_vcg_live_flags<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, (const float*)h->c.r, (const float*)h->c.d, h->n, h->off[1], h->off[2], flags);
+  else
+    hipLaunchKernelGGL((k_vcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, (const double*)h->c.r, (const double*)h->c.d, h->n, h->off[1], h->off[2], flags);
+  hipLaunchKernelGGL(k_vcg_live_list, dim3(1), dim3(1024), 0, st, flags, nchunks, list, count);
+  MFS_LAUNCH_CHECK();
+  int shift = 0;
+  while ((1 << shift) < kLiveChunk / vec) ++shift;
+  h->c.live = LiveMap{list, count, shift};
+  return MFS_OK;
+}
+
+// classes, tile flags and the cost-balanced cut of the marching kernel's compressed class access, once per set-up, at the
+// first launch that wants them (grids that run the resident small-grid loop never do: four launches less per solve)
+static int vcg_build_classes(mfs_vcg3d* h, hipStream_t stream) {
+  const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
+  unsigned char* mp = (unsigned char*)h->cp.msk;
+  h->classes_ready = true;
+  h->cp.tw_block = 0;
+  h->cp.seg_g = 0;
+  if (Nx >= 3 && Ny >= 3) {    // classes of the interior z-vectors for the march's compressed class access
+    const int vec = h->dt == MFS_F32 ? 4 : 2;
+    if (Nz % vec == 0 && Nz >= 2 * vec) {
+      MFS_HIP_TRY(hipMemsetAsync((void*)h->cp.bulk, 0, 8, stream));
+      const int gb = (int)std::min<int64_t>(1024, cdiv(h->cp.stored(), 256));
+      if (h->dt == MFS_F32) hipLaunchKernelGGL((k_vcg_bulk_value<float>), dim3(gb), dim3(256), 0, stream, h->cp, (float*)h->cp.bulk);
+      else hipLaunchKernelGGL((k_vcg_bulk_value<double>), dim3(gb), dim3(256), 0, stream, h->cp, (double*)h->cp.bulk);
+      const int64_t nvec = (int64_t)(Nx - 2) * (Ny - 2) * (Nz / vec);
+      if (h->dt == MFS_F32) hipLaunchKernelGGL((k_vcg_classify<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, stream, h->cp, mp);
+      else hipLaunchKernelGGL((k_vcg_classify<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, stream, h->cp, mp);
+      MFS_LAUNCH_CHECK();
+      // ... and the tile words, for the tile size the march will run with on this grid
+      const int geom = h->dt == MFS_F32 ? vcg_march_geom<float, 4>(h) : vcg_march_geom<double, 2>(h);
+      h->cp.tw_block = geom / 10;
+      if (h->cp.tw_block > 0) {
+        const int ipp = (Ny - 2) * (Nz / vec), tiles = (ipp + h->cp.tw_block - 1) / h->cp.tw_block;
+        const int64_t nt = (int64_t)tiles * Nx;
+        const int64_t gr[3] = {Nx, Ny, Nz};
+        MFS_REQUIRE((size_t)nt <= tile_words_bytes(gr, h->dt), "tile flags do not fit their workspace");
+        unsigned char* const flags = (unsigned char*)h->cp.tw;
+        if (vec == 4) hipLaunchKernelGGL((k_vcg_tile_flags<4>), dim3(cdiv(nt * kWave, 256)), dim3(256), 0, stream, h->cp, h->cp.tw_block, flags);
+        else hipLaunchKernelGGL((k_vcg_tile_flags<2>), dim3(cdiv(nt * kWave, 256)), dim3(256), 0, stream, h->cp, h->cp.tw_block, flags);
+        MFS_LAUNCH_CHECK();
+        // the cost-balanced cut for the grid the march will be launched with on this engine
+        const size_t ldsb = h->dt == MFS_F32 ? (size_t)(geom % 10) * 3 * (2 * Nz + h->cp.tw_block * 4) * 4
+                                             : (size_t)(geom % 10) * 3 * (2 * Nz + h->cp.tw_block * 2) * 8;
+        const int bpc = ldsb > 80 * 1024 ? 1 : h->march_bpc;
+        const int64_t total = (int64_t)tiles * (Nx - 2);
+        const int G = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * bpc));
+        h->cp.seg_g = 0;
+        if (G <= kVmMaxSegs && total < 0x7fffffff) {
+          hipLaunchKernelGGL(k_vcg_balance, dim3(1), dim3(1024), 0, stream, flags, tiles, Nx, G, (int*)h->cp.seg);
+          MFS_LAUNCH_CHECK();
+          h->cp.seg_g = G;
+        }
+      }
+    }
+  }
+  return MFS_OK;
+}
+
 template <typename T, int VEC, int WAVES>
 static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* partial, const double* done, hipStream_t st,
                             int* nparts) {
@@ -1076,7 +1215,8 @@ static int vcg_march_launch(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* par
   const int knob = h->march_nt;
   const bool nt = knob < 0 ? (13.0 * (double)h->g.N[0] * h->g.N[1] * h->g.N[2] * sizeof(T) > 200e6) : (knob != 0);
   if constexpr (VEC == VecOf<T>::N && WAVES == MFS_VMARCH_MIN_WAVES) {
-    // compressed class access (k_vcg_classify / k_vcg_tile_words ran at set-up, for this very tile size): fewer bytes
+    // compressed class access (classes, tile flags and the balanced cut built once per set-up, for this tile size)
+    if (h->compress && !h->classes_ready) { if (int e = vcg_build_classes(h, st)) return e; }
     if (h->compress && h->cp.tw_block > 0 && h->cp.tw_block == vcg_march_geom<T, VEC>(h) / 10)
       return nt ? vcg_march_launch_nt<T, VEC, WAVES, 5, false, true>(h, vv, ob, partial, done, st, nparts)
                 : vcg_march_launch_nt<T, VEC, WAVES, 0, false, true>(h, vv, ob, partial, done, st, nparts);
@@ -1513,6 +1653,7 @@ size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   tot += align_up((size_t)kMaxPartials * 8, 4096);                        // r.z partials (Jacobi loop)
   tot += vres_ws_bytes(mfs_vcg3d_dofs(gres), dtype_size(dt));             // resident loop: records + face mirror (0 if too big)
   tot += 4096;                                                            // the bulk volume value (compressed class access)
+  tot += live_ws_bytes(mfs_vcg3d_dofs(gres));                             // live chunks of the flat vectors
   tot += tile_words_bytes(gres, dt);                                      // its tile words
   tot += align_up((size_t)(kVmMaxSegs + 1) * sizeof(int), 4096);          // ... and the cost-balanced segment starts
   return tot;
@@ -1577,6 +1718,10 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->last_iters = 0;
   h->diag_ready = false;
   h->compress = env_int("MFS_VISC_COMPRESS", 1);
+  h->classes_ready = false;
+  h->sparse_vec = env_int("MFS_VISC_SPARSE", 1);
+  h->sparse_min = (int64_t)env_int("MFS_VISC_SPARSE_MIN", 1 << 21);
+  h->live_ws = (int*)p; p += live_ws_bytes(h->n);
   h->march_nt = env_int("MFS_VISC_MARCH_NT", -1);
   h->fuse = env_int("MFS_VISC_FUSE", 0);   // measured slower than the three-launch loop: opt-in
   h->fused_run = false;
@@ -1629,44 +1774,7 @@ int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int
                        h->cp.pz, sphi, sphi_dt, vol, vol_dt, (double*)v[1], (double*)v[2], (double*)v[3], (double*)v[4],
                        (double*)v[5], (double*)v[6], (double*)v[7], mp);
   MFS_LAUNCH_CHECK();
-  if (Nx >= 3 && Ny >= 3) {    // classes of the interior z-vectors for the march's compressed class access
-    const int vec = h->dt == MFS_F32 ? 4 : 2;
-    if (Nz % vec == 0 && Nz >= 2 * vec) {
-      MFS_HIP_TRY(hipMemsetAsync((void*)h->cp.bulk, 0, 8, (hipStream_t)stream));
-      const int gb = (int)std::min<int64_t>(1024, cdiv(h->cp.stored(), 256));
-      if (h->dt == MFS_F32) hipLaunchKernelGGL((k_vcg_bulk_value<float>), dim3(gb), dim3(256), 0, (hipStream_t)stream, h->cp, (float*)h->cp.bulk);
-      else hipLaunchKernelGGL((k_vcg_bulk_value<double>), dim3(gb), dim3(256), 0, (hipStream_t)stream, h->cp, (double*)h->cp.bulk);
-      const int64_t nvec = (int64_t)(Nx - 2) * (Ny - 2) * (Nz / vec);
-      if (h->dt == MFS_F32) hipLaunchKernelGGL((k_vcg_classify<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, mp);
-      else hipLaunchKernelGGL((k_vcg_classify<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, mp);
-      MFS_LAUNCH_CHECK();
-      // ... and the tile words, for the tile size the march will run with on this grid
-      const int geom = h->dt == MFS_F32 ? vcg_march_geom<float, 4>(h) : vcg_march_geom<double, 2>(h);
-      h->cp.tw_block = geom / 10;
-      if (h->cp.tw_block > 0) {
-        const int ipp = (Ny - 2) * (Nz / vec), tiles = (ipp + h->cp.tw_block - 1) / h->cp.tw_block;
-        const int64_t nt = (int64_t)tiles * Nx;
-        const int64_t gr[3] = {Nx, Ny, Nz};
-        MFS_REQUIRE((size_t)nt <= tile_words_bytes(gr, h->dt), "tile flags do not fit their workspace");
-        unsigned char* const flags = (unsigned char*)h->cp.tw;
-        if (vec == 4) hipLaunchKernelGGL((k_vcg_tile_flags<4>), dim3(cdiv(nt * kWave, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, h->cp.tw_block, flags);
-        else hipLaunchKernelGGL((k_vcg_tile_flags<2>), dim3(cdiv(nt * kWave, 256)), dim3(256), 0, (hipStream_t)stream, h->cp, h->cp.tw_block, flags);
-        MFS_LAUNCH_CHECK();
-        // the cost-balanced cut for the grid the march will be launched with on this engine
-        const size_t ldsb = h->dt == MFS_F32 ? (size_t)(geom % 10) * 3 * (2 * Nz + h->cp.tw_block * 4) * 4
-                                             : (size_t)(geom % 10) * 3 * (2 * Nz + h->cp.tw_block * 2) * 8;
-        const int bpc = ldsb > 80 * 1024 ? 1 : h->march_bpc;
-        const int64_t total = (int64_t)tiles * (Nx - 2);
-        const int G = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)h->c.cus * bpc));
-        h->cp.seg_g = 0;
-        if (G <= kVmMaxSegs && total < 0x7fffffff) {
-          hipLaunchKernelGGL(k_vcg_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, flags, tiles, Nx, G, (int*)h->cp.seg);
-          MFS_LAUNCH_CHECK();
-          h->cp.seg_g = G;
-        }
-      }
-    }
-  }
+  h->classes_ready = false;    // the march's compressed class access builds its classes at its first launch (vcg_build_classes)
   h->k1 = scale * mu;          // `scale * mu * ...`      (left to right, as the reference evaluates it)
   h->k2 = 2 * scale * mu;      // `2 * scale * mu * ...`
   h->is_setup = true;
@@ -1702,6 +1810,7 @@ int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
   h->fused_run = false;
+  h->c.live = LiveMap{nullptr, nullptr, 0};
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;     // x keeps the extrapolated velocity (:569-573)
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;   // :575
@@ -1722,7 +1831,8 @@ int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
     return MFS_OK;
   }
   if (int e = core_begin_post(h->c, st)) return e;                // :577-585
-  return core_begin_finish(h->c, st);
+  if (int e = core_begin_finish(h->c, st)) return e;
+  return (h->p2p || h->skip_top_x || h->fuse) ? MFS_OK : vcg_build_live(h, st);      // single-domain, launch-per-phase loops only
 }
 
 // ---- slab decomposition along x (mfs/dist.py:SlabVCG): the phases of one iteration, so that the caller can put the
@@ -1741,6 +1851,7 @@ int mfs_vcg3d_begin_local(mfs_vcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
   h->fused_run = false;
+  h->c.live = LiveMap{nullptr, nullptr, 0};      // slab loops sweep every chunk (ghost planes of d arrive from the neighbours)
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
@@ -1795,6 +1906,8 @@ int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   ++h->p2p->epoch;
   hipStream_t st = (hipStream_t)stream;
   h->fused_run = false;
+  h->c.live = LiveMap{nullptr, nullptr, 0};
+  h->c.live = LiveMap{nullptr, nullptr, 0};      // slab loops sweep every chunk (ghost planes of d arrive from the neighbours)
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
@@ -2100,6 +2213,7 @@ int mfs_vcg3d_set_compress(mfs_vcg3d* h, int on) {
 int mfs_vcg3d_class_census(mfs_vcg3d* h, int64_t counts_host[3], mfs_stream stream) {
   MFS_REQUIRE(h && counts_host, "null argument");
   MFS_REQUIRE(h->is_setup, "mfs_vcg3d_setup has not been called");
+  if (!h->classes_ready) { if (int e = vcg_build_classes(h, (hipStream_t)stream)) return e; }
   counts_host[0] = counts_host[1] = counts_host[2] = 0;
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2], vec = h->dt == MFS_F32 ? 4 : 2;
   if (Nx < 3 || Ny < 3 || Nz % vec != 0 || Nz < 2 * vec) return MFS_OK;       // no marching kernel, no classes

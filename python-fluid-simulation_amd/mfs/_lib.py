@@ -107,6 +107,11 @@ SIGNATURES = {
     "mfs_p2p_destroy": (_i, [_p]),
     "mfs_pcg3d_attach_p2p": (_i, [_p, _p]),
     "mfs_pcg3d_slab_supported": (_i, [_p]),
+    "mfs_rccl_unique_id_bytes": (_i, []),
+    "mfs_rccl_unique_id": (_i, [C.c_char_p, _p]),
+    "mfs_rccl_create": (_i, [C.POINTER(_p), C.c_char_p, _p, _i, _i]),
+    "mfs_rccl_destroy": (_i, [_p]),
+    "mfs_pcg3d_attach_rccl": (_i, [_p, _p, _p]),
     "mfs_pcg3d_slab_set_aux": (_i, [_p, _i]),
     "mfs_pcg3d_slab_begin": (_i, [_p, _d, _p]),
     "mfs_pcg3d_slab_iterate": (_i, [_p, _i64, _p]),
@@ -165,6 +170,7 @@ SIGNATURES = {
     "mfs_particle_tile_sort3d": (_i, [_pi64, _pd, _pd, _p, _i, _i64, _p, _p, _p, _p]),
     "mfs_p2g_scatter3d_tiled": (_i, [_pi64, _pd, _pd, _pd, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i64, _p, _p, _p, _p, _i, _p]),
     "mfs_fluid_levelset3d_tiled": (_i, [_pi64, _pd, _pd, _d, _p, _i, _i64, _p, _p, _p, _i, _p]),
+    "mfs_density_splat3d_tiled": (_i, [_pi64, _pd, _pd, _p, _i, _p, _i, _d, _i64, _p, _p, _p, _p, _i, _p]),
     "mfs_fluid_volume3d_tiled": (_i, [_pi64, _pd, _pd, _p, _i, _d, _i64, _p, _p, _p, _i, _p]),
     "mfs_g2p_gather3d": (_i, [_pi64, _pd, _pd, _pd, _i, _p, _i, _p, _i, _p, _i, _i64, _p, _i, _p]),
     "mfs_fluid_levelset3d": (_i, [_pi64, _pd, _pd, _d, _p, _i, _i64, _p, _i, _p]),

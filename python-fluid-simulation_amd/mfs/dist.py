@@ -142,8 +142,15 @@ class SlabCG(_BoundedCollectives):
     all-reduces act on.  `d` is the local direction vector (planes 0 and L-1 are
     the ghost / boundary planes).  `dist` is torch.distributed or None (1 rank)."""
 
-    def __init__(self, ops, part, d, dist=None, group=None, overlap=True, force_multi=False, window=None):
+    def __init__(self, ops, part, d, dist=None, group=None, overlap=True, force_multi=False, window=None, rccl=None):
+        """window: a connected mfs.p2p.P2PWindow -> the native window loop ("p2p").  rccl: an mfs.rccl.RcclComm -> the
+        native COLLECTIVE loop ("rccl", round 3): the window loop's launches, halo planes and dot products through RCCL
+        between them, enqueued from C.  Neither: the phase-by-phase loop below with torch.distributed collectives."""
         self.ops, self.part, self.d, self.dist, self.group = ops, part, d, dist, group
+        self.rccl = rccl
+        if rccl is not None and window is None:
+            from .rccl import LocalWindow
+            window = LocalWindow(int(d[0].numel()) * d.element_size(), d.device)
         self.overlap = overlap
         self.L = int(d.shape[0])
         if self.L != part.local_planes:
@@ -154,16 +161,28 @@ class SlabCG(_BoundedCollectives):
         # halo planes and dot products moving as xGMI stores between the solver's own kernels
         # (csrc/mfs_pcg_slab.h); without one, the phase-by-phase loop below with RCCL collectives
         self.window = window if (window is not None and window.ok) else None
-        if self.window is not None:
-            ops.attach_p2p(self.window)
+        self._attach()
         self._bc_init()
         self._p2p_active = None          # which loop the last begin() / solve() took (None: none yet)
         self.downgraded = ""             # why a given window is NOT being used (empty: it is, or none was given)
+
+    def _attach(self):
+        """point the engine at THIS driver's transport (several drivers may share one engine: bench.py's cross-checks)"""
+        if self.window is None:
+            return
+        if self.rccl is not None:
+            self.ops.attach_rccl(self.window, self.rccl)
+        else:
+            if hasattr(self.ops, "attach_rccl") and getattr(self.ops, "_rccl", None) is not None:
+                self.ops.attach_rccl(None, None)
+            self.ops.attach_p2p(self.window)
 
     @property
     def mode(self):
         """the transport of the loop that runs: after begin() / solve() what was taken, before it what would be"""
         p2p = self._p2p_active if self._p2p_active is not None else self._p2p()
+        if p2p and self.rccl is not None:
+            return "rccl"                 # the native collective loop
         return "p2p" if p2p else ("rccl" if (self.multi or (self.window is not None and self.dist is not None)) else "single")
 
     def _note_downgrade(self):
@@ -218,8 +237,11 @@ class SlabCG(_BoundedCollectives):
         return self.window is not None and self.ops.slab_supported()
 
     def begin(self, tol):
+        self._attach()
         if self._p2p():
             self._p2p_active = True
+            if self.rccl is not None:
+                self._drop_jacobi()
             self.ops.slab_begin(tol)
             return
         self._p2p_active = False
@@ -282,9 +304,23 @@ class SlabCG(_BoundedCollectives):
     def solve(self, tol, max_iter, check_every=32):
         """begin + iterate until the device-resident `done` flag or max_iter; returns (converged, iterations).
         COLLECTIVE.  The scalars every rank tests are bit-identical, so all ranks leave the loop together."""
-        if self._p2p():
+        self._attach()
+        if self._p2p() and self.rccl is None:
             self._p2p_active = True
             return self.ops.slab_solve(tol, max_iter, check_every)
+        if self._p2p():      # native collective loop: the same batches, every host wait bounded (a lost peer stalls RCCL)
+            self.begin(tol)
+            self.drain()
+            st = self.ops.poll()
+            enq = 0
+            while not st["done"] and enq < max_iter:
+                n = min(int(check_every), int(max_iter) - enq)
+                self.iterate(n)
+                enq += n
+                self.drain()
+                st = self.ops.poll()
+            self.ops.finish()
+            return bool(st["done"]), int(st["iterations"])
         self._p2p_active = False
         if self.window is not None and self.dist is not None:
             self._note_downgrade()

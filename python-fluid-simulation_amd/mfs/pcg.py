@@ -202,6 +202,12 @@ class PcgEngine:
                    "mfs_pcg3d_attach_p2p")
         self._window = window     # keep it alive while the engine points at it
 
+    def attach_rccl(self, own_window, comm):
+        """collective transport of the slab loop: this rank's own one-rank window + an mfs.rccl.RcclComm (None, None detaches)"""
+        _lib.check(self.lib.mfs_pcg3d_attach_rccl(self.h, own_window.h if own_window is not None else None,
+                                                  comm.h if comm is not None else None), "mfs_pcg3d_attach_rccl")
+        self._window, self._rccl = own_window, comm
+
     def slab_supported(self):
         return bool(self.lib.mfs_pcg3d_slab_supported(self.h))
 

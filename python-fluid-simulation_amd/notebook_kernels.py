@@ -73,29 +73,39 @@ def _f3(a):
 TILE_MIN_PARTICLES = int(os.environ.get("MFS_PARTICLE_TILE_MIN", "262144"))
 
 
+_TILE_ORDERS = []      # [(key, perm, tile_start, work)], most recent first: the orders of the last two position tensors
+
+
 def tile_order(p, gres, bound_min, cell_size):
-    """(perm, tile_start) of p.x on the CELL grid `gres` -- int32 device tensors -- or None below TILE_MIN_PARTICLES"""
-    px = _particles(p.x, "p.x")
+    """(perm, tile_start) of the particle positions `p.x` (or the (P,3) tensor `p` itself) on the CELL grid `gres` -- int32
+    device tensors -- or None below TILE_MIN_PARTICLES.  Cached by tensor identity and version: every consumer of one
+    position update (level set, volume, density splat, p2g) shares one sort."""
+    px = _particles(p.x if hasattr(p, "x") else p, "p.x")
     P = int(px.shape[0])
     if P < TILE_MIN_PARTICLES:
         return None
     g = tuple(int(v) for v in gres)
     geo = tuple(T.as_f64_list(bound_min, 3)) + tuple(T.as_f64_list(cell_size, 3))
-    key = (px.data_ptr(), px._version, P, g, geo)
-    c = getattr(p, "_mfs_tile_order", None)
-    if c is not None and c[0] == key:
-        return c[1], c[2]
+    key = (px.data_ptr(), px._version, P, g, geo, str(px.device))
+    for i, ent in enumerate(_TILE_ORDERS):
+        if ent[0] == key:
+            if i:
+                _TILE_ORDERS.insert(0, _TILE_ORDERS.pop(i))
+            return ent[1], ent[2]
     lib = _lib.load()
     nt = int(lib.mfs_particle_tiles3d(_lib.i64x(g)))
-    bufs = getattr(p, "_mfs_tile_bufs", None)
-    if bufs is None or bufs[0].numel() != P or bufs[1].numel() != nt + 1:
+    bufs = None
+    if len(_TILE_ORDERS) >= 2:           # recycle the older entry's buffers when they fit
+        old = _TILE_ORDERS.pop()
+        if old[1].numel() == P and old[2].numel() == nt + 1 and old[1].device == px.device:
+            bufs = old[1:]
+    if bufs is None:
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=px.device)  # noqa: E731
         bufs = (i32(P), i32(nt + 1), i32(2 * nt + P))
-        p._mfs_tile_bufs = bufs
     perm, tstart, work = bufs
     _lib.check(lib.mfs_particle_tile_sort3d(_lib.i64x(g), _f3(bound_min), _f3(cell_size), T.ptr(px), T.code(px), P, T.ptr(perm),
                                             T.ptr(tstart), T.ptr(work), T.stream()), "mfs_particle_tile_sort3d")
-    p._mfs_tile_order = (key, perm, tstart)
+    _TILE_ORDERS.insert(0, (key, perm, tstart, work))
     return perm, tstart
 
 

@@ -40,6 +40,16 @@ def initialize_density(bound_min, cell_size, gres, px, pm, pvol, gm, gvol, sphi=
     if gm.dtype != gvol.dtype:
         raise TypeError("gm and gvol must share a dtype")
     lib = _lib.load()
+    # at millions of particles: one workgroup per tile of 8^3 cells, the tile's cells in LDS (csrc/mfs_density.hip) on the
+    # tile order notebook_kernels keeps for the particle positions (same order as p2g / level set / volume use)
+    import notebook_kernels as NK
+    order = NK.tile_order(px, g, bound_min, cell_size)
+    if order is not None:
+        _lib.check(lib.mfs_density_splat3d_tiled(_lib.i64x(g), _lib.f64x(T.as_f64_list(bound_min, 3)),
+                                                 _lib.f64x(T.as_f64_list(cell_size, 3)), T.ptr(px), T.code(px), T.ptr(pm),
+                                                 T.code(pm), float(pvol), int(px.shape[0]), T.ptr(order[0]), T.ptr(order[1]),
+                                                 T.ptr(gm), T.ptr(gvol), T.code(gm), T.stream()), "mfs_density_splat3d_tiled")
+        return
     _lib.check(lib.mfs_density_splat3d(_lib.i64x(g), _lib.f64x(T.as_f64_list(bound_min, 3)),
                                        _lib.f64x(T.as_f64_list(cell_size, 3)), T.ptr(px), T.code(px), T.ptr(pm),
                                        T.code(pm), float(pvol), int(px.shape[0]), T.ptr(gm), T.ptr(gvol), T.code(gm),

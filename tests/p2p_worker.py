@@ -206,6 +206,45 @@ def rccl_world1_mode(rank, world, path, out, dtname, dev):
     timestep_sharded_mode(rank, world, path, out, dtname, dev)
 
 
+def rccl_native_mode(rank, world, path, out, dtname, dev, tdt):
+    """the NATIVE collective slab loop (csrc/mfs_rccl.h) on a one-rank RCCL communicator (all one GPU admits) against the
+    window loop on a one-rank window and the phase-by-phase collective loop: same launches, same partial sums -- the window
+    loop's history bit for bit, the phase loop's to rounding; begin / iterate / finish and solve()"""
+    from mfs.rccl import RcclComm
+    assert dist.get_backend() == "nccl" and world == 1
+    with np.load(path, allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    gres = tuple(int(v) for v in g["gres"])
+    part = SlabPartition(gres[0], 1, 0)
+    T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), device=dev).to(dt)  # noqa: E731
+    eng = PcgEngine(gres, tdt, dev)
+    eng.setup(T(g["lphi"]), T(g["wx"]), T(g["wy"]), T(g["wz"]))
+    bt = T(g["b"], tdt)
+    x, d, r, q = (torch.zeros(gres, dtype=tdt, device=dev) for _ in range(4))
+    eng.bind(bt, x, d, r, q)
+    win = P2PWindow(dist, gres[1] * gres[2] * bt.element_size(), dev)
+    assert win.ok, win.why
+    comm = RcclComm(dist, dev)
+    res = {}
+    for name, cg in (("window", SlabCG(eng, part, d, dist, force_multi=True, window=win)),
+                     ("native", SlabCG(eng, part, d, dist, force_multi=True, rccl=comm)),
+                     ("phases", SlabCG(eng, part, d, dist, force_multi=True))):
+        cg.begin(0.0)
+        cg.iterate(3)
+        cg.iterate(9)
+        cg.finish()
+        torch.cuda.synchronize()
+        res[name + "_hist"], res[name + "_x"], res[name + "_mode"] = eng.history()[:25], x.cpu().numpy().astype(np.float64), cg.mode
+    # ... and a whole solve through the native loop
+    cg = SlabCG(eng, part, d, dist, force_multi=True, rccl=comm)
+    ok, it = cg.solve(float(g["tol"]), int(np.prod(gres)), 8)
+    torch.cuda.synchronize()
+    res["solve_ok"], res["solve_iters"], res["solve_x"], res["solve_hist"] = int(ok), it, x.cpu().numpy().astype(np.float64), eng.history()
+    np.savez(f"{out}.rank{rank}.npz", **res)
+    comm.close()
+    win.close()
+
+
 def _close_after_fault(win):
     """teardown of the fault-injection modes: the group may be broken by the timed-out collective (gloo closes the
     pair), so the window's closing barrier is best-effort and the process leaves without a collective teardown."""
@@ -231,6 +270,12 @@ def main():
                                 timeout=pg_timeout())
     else:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=pg_timeout())
+    if os.environ.get("P2P_TEST_MODE") == "rccl_native":
+        try:
+            rccl_native_mode(rank, world, path, out, dtname, dev, tdt)
+        finally:
+            dist.destroy_process_group()
+        return
     if os.environ.get("P2P_TEST_MODE") == "rccl_world1":
         try:
             rccl_world1_mode(rank, world, path, out, dtname, dev)

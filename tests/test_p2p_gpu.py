@@ -232,3 +232,30 @@ def test_slab_p2p_jacobi(name, world, dtname, defer, tmp_path):
     np.testing.assert_allclose(h[:n], h0[:n], rtol=1e-10 if dtname == "f64" else 1e-5)
     assert abs(int(res[0]["iters"]) - it0) <= max(2, it0 // 10)
     np.testing.assert_allclose(x, x0, rtol=0, atol=(1e-4 if dtname == "f64" else 1e-3) * np.abs(x0).max())
+
+
+@pytest.mark.parametrize("name,dtname", [("p3d_d_20", "f64"), ("p3d_d_20", "f32"), ("p3d_f_40x36x32_sv", "f64")])
+def test_native_collective_loop_on_a_one_rank_communicator(name, dtname, tmp_path):
+    """round 3: the collective transport as a NATIVE loop -- the window loop's four launches with
+    ncclSend / ncclRecv of the edge planes and one ncclAllReduce per dot product between them, enqueued from C
+    (csrc/mfs_rccl.h).  RCCL admits one rank per device, so: a one-rank communicator of the build's own (bootstrap over a
+    real "nccl" torch.distributed group) -- every launch, every RCCL call except the peer transfers -- against the window
+    loop on a one-rank window (same launches and partial sums: bit for bit) and the phase-by-phase collective loop
+    (rounding).  solve() converges to the golden's iteration count and solution."""
+    require_default_engine("test_native_collective_loop_on_a_one_rank_communicator")
+    g = golden(name)
+    r = _run_ranks(name, 1, tmp_path, dtname, P2P_TEST_MODE="rccl_native", P2P_TEST_BACKEND="nccl")[0]
+    assert str(r["window_mode"]) == "p2p" and str(r["native_mode"]) == "rccl" and str(r["phases_mode"]) == "rccl"
+    np.testing.assert_array_equal(r["native_hist"], r["window_hist"])
+    np.testing.assert_array_equal(r["native_x"], r["window_x"])
+    tol = 1e-9 if dtname == "f64" else 1e-4
+    n = 21
+    np.testing.assert_allclose(r["native_hist"][:n], r["phases_hist"][:n], rtol=tol)
+    assert int(r["solve_ok"]) == 1
+    it = int(g["iters"])
+    assert abs(int(r["solve_iters"]) - it) <= max(2, it // 10) if dtname == "f64" else int(r["solve_iters"]) <= 1.5 * it + 2
+    xg = g["x"]
+    np.testing.assert_allclose(r["solve_x"], xg, rtol=0, atol=1e-4 * np.abs(xg).max())
+    hg = g["history"]
+    w = 17 if dtname == "f32" else 21
+    np.testing.assert_allclose(r["solve_hist"][:w], hg[:w], rtol=1e-9 if dtname == "f64" else 1e-5)

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import require_default_engine
+
 from mfs import scenes
 from oracle import mfs_oracle as O
 

@@ -22,6 +22,8 @@ def _solver(gres, sc, dt, fuse):
     s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision=dt, device=DEV, check_every=8)
     s._engine.set_fuse(fuse)
     s._engine.set_resident(False)
+    s._engine.set_compress(False)      # (round 3) the compressed march cuts its work into cost-balanced segments: another grouping of d.q.
+                                       # The fused launch has no compressed form, so both loops are compared on dense access
     s._engine.set_merged(False)        # the reference form here is the THREE-launch loop (the merged vector phases group r.r differently)
     return s
 
