@@ -199,6 +199,14 @@ int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
 /* form of the native loop for the engine as bound: bit 0 = direction update fused into the stencil launch,
  * bit 1 = x update deferred into it too, bit 2 = Jacobi loop, bit 3 = resident small-grid loop (mfs_pcg3d_set_resident) */
 int mfs_pcg3d_loop_info(mfs_pcg3d* h);
+/* sparse lists of a single-domain solve (round 3; default on from 2^21 cells, env MFS_SPARSE / MFS_SPARSE_MIN): behind the
+ * initial residual mfs_pcg3d_begin lists the 1024-cell chunks holding a live z-vector (row not ZERO, or r, d != 0) and the
+ * (tile, plane) pairs of the march holding one; the r update sweeps the listed chunks, the fused stencil launches visit the
+ * listed pairs.  Dead vectors keep q = r = d = +0 and x unchanged, which is what the dense loop computes for them; the dot
+ * products group differently (rounding).  Slab loops, begin_local / phase callers and the Jacobi loop stay dense.
+ * mfs_pcg3d_sparse_info (host-synchronous): out = {listed chunks, chunks, listed pairs, pairs}; zeros where a list is off. */
+int mfs_pcg3d_set_sparse(mfs_pcg3d* h, int on);
+int mfs_pcg3d_sparse_info(mfs_pcg3d* h, mfs_stream stream, int64_t out[4]);
 /* OPT-IN Jacobi preconditioning of the native loop (default off; env MFS_JACOBI=1): delta = r.z with z = r / diag,
  * convergence test unchanged (r.r < tol^2).  Fused form (default where the fused direction update is available): the r
  * update stores z and closes the iteration, the next stencil launch forms d = z + beta d (2 launches per iteration);

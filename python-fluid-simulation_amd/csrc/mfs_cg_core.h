@@ -76,6 +76,46 @@ __device__ __forceinline__ int64_t live_vec(const LiveMap& lm, int64_t k) {
   return lm.list ? (((int64_t)lm.list[k >> lm.shift] << lm.shift) | (k & ((1 << lm.shift) - 1))) : k;
 }
 
+constexpr int kLiveChunk = 1024;          // unknowns per chunk of a live map
+
+// chunk flags -> list of live chunk indices + their count (ONE block; a few ten thousand chunks at most)
+template <typename F>
+static __global__ void __launch_bounds__(1024)
+k_live_list(const F* __restrict__ flags, int nchunks, int* __restrict__ list, int* __restrict__ count) {
+  const int t = threadIdx.x;
+  const int per = (nchunks + 1023) / 1024, i0 = min(nchunks, t * per), i1 = min(nchunks, i0 + per);
+  int sum = 0;
+  for (int i = i0; i < i1; ++i) sum += flags[i] != 0;
+  __shared__ int s_pre[1024];
+  s_pre[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? s_pre[t - o] : 0;
+    __syncthreads();
+    s_pre[t] += v;
+    __syncthreads();
+  }
+  int run = s_pre[t] - sum;
+  for (int i = i0; i < i1; ++i)
+    if (flags[i] != 0) list[run++] = i;
+  if (t == 1023) *count = s_pre[1023];
+}
+
+// work lists of the marching kernels: runrem[k] = how many consecutive list entries from k on are consecutive planes of one
+// tile (one march); `np` = planes per tile in the numbering of the entries
+static __global__ void __launch_bounds__(256)
+k_list_runs(const int* __restrict__ items, const int* __restrict__ count, int np, int* __restrict__ runrem) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *count;
+  if (k >= n) return;
+  const int it = items[k], tile = it / np;
+  int r = 1;
+  while (k + r < n && items[k + r] == it + r && (it + r) / np == tile) ++r;
+  runrem[k] = r;
+}
+
+static inline size_t core_live_ws_bytes(int64_t n) { return align_up((size_t)(2 * ((n + kLiveChunk - 1) / kLiveChunk) + 64) * sizeof(int), 4096); }
+
 template <typename T, int VEC, typename F>
 __device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = false, bool blocked = false, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   // f(i, vec): process elements [i, i+VEC) (vec) or the single element i (tail).

@@ -115,6 +115,11 @@ struct mfs_pcg3d {
   // the xGMI stores (whose completion the producing kernel has to wait for) overlap the interior stencil launch
   hipStream_t aux;
   hipEvent_t ev_main, ev_aux;
+  const int *skip_items, *skip_runrem, *skip_count;   // sparse work list of the fused stencil launches (null: dense), per solve
+  int* skip_ws;                // tile flags | items | runrem | count
+  int sparse_vec;              // 1 (default; MFS_SPARSE): the r update of a single-domain solve sweeps live chunks only (LiveMap)
+  int64_t sparse_min;          // ... from this many cells on
+  int* live_ws;                // flags | list | count
   mfs_rccl* rccl;              // collective transport of the slab loop (mfs_pcg3d_attach_rccl): the attached window is then this
                                // rank's OWN 1-rank window, halo planes and dot products travel through RCCL between the launches
   int use_aux;
@@ -140,6 +145,11 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
   if (variant >= 2 && lds > 64 * 1024) variant = 1;          // absurdly long rows: skip the LDS image
   const int xchunk = std::max(0, h->xchunk);   // 0 = no cap on the length of one march
   ApplyArgs a{h->Nx, h->Ny, h->Nz, xb, xe, xchunk, xb2, xe2};
+  // sparse work list (built behind the initial residual of a single-domain solve): the fused launches of the loop visit
+  // only (tile, plane) pairs that compute anything.  The launch's range must be the list's: all computed planes, one range.
+  if (fz && h->skip_items && h->compress != 0 && VEC > 1 && xb == 1 && xe == h->Nx - 1 && xe2 == xb2 && variant >= 2) {
+    a.items = h->skip_items; a.runrem = h->skip_runrem; a.count = h->skip_count;
+  }
   const int np = (xe - xb) + (xe2 - xb2);
   if (variant == 0) {
     const int64_t items = (int64_t)np * ipp;
@@ -257,13 +267,21 @@ static int apply_dispatch(mfs_pcg3d* h, const void* v, void* out, int64_t xb, in
                           : launch_apply<double>(h, v, out, b, e, b2, e2, partial, use_done, st, grid_out, fz);
 }
 
+// (tile, plane) pairs of the marching kernel on this grid: tiles of kApplyBlock z-vectors per interior plane x Nx
+static int64_t skip_pairs(const int64_t gres[3], int dt) {
+  const int64_t vec = dt == MFS_F32 ? 4 : 2;
+  return ((gres[1] * (gres[2] / vec + 1) + kApplyBlock - 1) / kApplyBlock + 1) * (gres[0] + 1);
+}
+static size_t skip_ws_bytes(const int64_t gres[3], int dt) { return align_up((size_t)(3 * skip_pairs(gres, dt) + 64) * sizeof(int), 4096); }
+
 extern "C" {
 
 size_t mfs_pcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   if (!gres || !dtype_ok(dt)) return 0;
   const int64_t n = gres[0] * gres[1] * gres[2];
   return core_ws_bytes() + 7 * coef_stride(n, dtype_size(dt)) + 4096 + align_up((size_t)n, 4096) +
-         align_up((size_t)kMaxPartials * 8, 4096) + res_ws_bytes(n, dtype_size(dt));
+         align_up((size_t)kMaxPartials * 8, 4096) + res_ws_bytes(n, dtype_size(dt)) + core_live_ws_bytes(n) +
+         skip_ws_bytes(gres, dt);
 }
 
 int64_t mfs_pcg3d_history_capacity(void) { return kHistCap; }
@@ -304,6 +322,11 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
     h->res_mirror = (u64*)(rp + align_up((size_t)kResRing * kResMaxW * kResRecStrideMax * 8, 4096));
     h->res = res_plan(h->Nx, h->Ny, h->Nz, dt == MFS_F32 ? 4 : 2, h->c.elt, h->res_w);
   }
+  h->live_ws = (int*)((char*)h->part_rz + align_up((size_t)kMaxPartials * 8, 4096) + res_ws_bytes(h->n, h->c.elt));
+  h->skip_ws = (int*)((char*)h->live_ws + core_live_ws_bytes(h->n));
+  h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
+  h->sparse_vec = env_int("MFS_SPARSE", 1);
+  h->sparse_min = (int64_t)env_int("MFS_SPARSE_MIN", 1 << 21);
   h->jacobi = env_int("MFS_JACOBI", 0);
   h->last_iters = 0;
   h->defer_x = env_int("MFS_DEFER_X", -1);
@@ -522,6 +545,8 @@ int mfs_pcg3d_begin_local(mfs_pcg3d* h, double tol, mfs_stream stream) {
   h->x_owed = false;
   h->book_pending = false;
   h->slab_loop = false;
+  h->c.live = LiveMap{nullptr, nullptr, 0};      // (slab loops and callers that drive the phases themselves sweep every chunk)
+  h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;
@@ -535,6 +560,80 @@ int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream) {
 }
 
 }  // extern "C"
+
+static bool native_fuse_ok(const mfs_pcg3d* h);
+
+// ---- live chunks of the cell vectors (mfs_cg_core.h LiveMap): a z-vector is DEAD when every computed cell of it is a
+// ZERO row (not fluid: k_pcg_classify) and r = d = 0 there at the start of the loop -- q, r and d then stay exactly 0 for the
+// whole solve.  The fused stencil launch still sweeps every vector (it owns the direction and x updates); the r update,
+// a pure streaming kernel, sweeps the live chunks only.  Single-domain loops; built behind the initial residual.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+k_pcg_live_flags(const unsigned char* __restrict__ cls, const T* __restrict__ r, const T* __restrict__ d, int64_t n, int* __restrict__ flags,
+                 int Nx, int Ny, int nzv, int* __restrict__ tflags) {
+  const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i0 = iv * VEC;
+  bool live = false;
+  if (i0 < n) {
+    live = cls[iv] != kClsZero;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) live = live || r[i0 + j] != (T)0 || d[i0 + j] != (T)0;
+    if (live && tflags) {      // ... and the march's (tile, plane) pair of this vector (interior vectors only: the others are never computed)
+      const int zv = (int)(iv % nzv), y = (int)((iv / nzv) % Ny), x = (int)(iv / ((int64_t)nzv * Ny));
+      if (x >= 1 && x <= Nx - 2 && y >= 1 && y <= Ny - 2) tflags[(int64_t)(((y - 1) * nzv + zv) / kApplyBlock) * (Nx - 2) + (x - 1)] = 1;
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(live) != 0 && (threadIdx.x & 63) == 0) {
+    const int64_t c0 = i0 / kLiveChunk, c1 = min(n - 1, i0 + 64 * VEC - 1) / kLiveChunk;
+    flags[c0] = 1;
+    if (c1 != c0) flags[c1] = 1;
+  }
+}
+
+static int pcg_build_live(mfs_pcg3d* h, hipStream_t st) {
+  h->c.live = LiveMap{nullptr, nullptr, 0};
+  h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
+  if (!h->sparse_vec || !h->compress || !h->vec_ok || !core_vec_ok(h->c) || h->n < h->sparse_min || h->jacobi) return MFS_OK;
+  const int vec = h->dt == MFS_F32 ? 4 : 2;
+  const int nchunks = (int)((h->n + kLiveChunk - 1) / kLiveChunk);
+  int* flags = h->live_ws;
+  int* list = flags + nchunks;
+  int* count = list + nchunks;
+  MFS_HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nchunks * sizeof(int), st));
+  // the fused stencil launches' work list: (tile, plane) pairs with a live vector, tile-major
+  const int nzv = h->Nz / vec, np = h->Nx - 2;
+  const int64_t ipp = (int64_t)(h->Ny - 2) * nzv;
+  const int tiles = (int)((ipp + kApplyBlock - 1) / kApplyBlock);
+  const int64_t gr[3] = {h->Nx, h->Ny, h->Nz};
+  const int64_t npairs = (int64_t)tiles * np;
+  const bool skip = h->Nx >= 3 && h->Ny >= 3 && npairs > 0 && npairs <= skip_pairs(gr, h->dt) && npairs < 0x7fffffff && native_fuse_ok(h);
+  int* tflags = h->skip_ws;
+  int* items = tflags + npairs;
+  int* runrem = items + npairs;
+  int* scount = runrem + npairs;
+  if (skip) MFS_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)npairs * sizeof(int), st));
+  const int64_t nvec = h->n / vec;
+  if (h->dt == MFS_F32)
+    hipLaunchKernelGGL((k_pcg_live_flags<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls, (const float*)h->c.r, (const float*)h->c.d, h->n, flags,
+                       h->Nx, h->Ny, nzv, skip ? tflags : (int*)nullptr);
+  else
+    hipLaunchKernelGGL((k_pcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls, (const double*)h->c.r, (const double*)h->c.d, h->n, flags,
+                       h->Nx, h->Ny, nzv, skip ? tflags : (int*)nullptr);
+  hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, flags, nchunks, list, count);
+  MFS_LAUNCH_CHECK();
+  int shift = 0;
+  while ((1 << shift) < kLiveChunk / vec) ++shift;
+  h->c.live = LiveMap{list, count, shift};
+  if (skip) {
+    hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, tflags, (int)npairs, items, scount);
+    hipLaunchKernelGGL(k_list_runs, dim3(cdiv(npairs, 256)), dim3(256), 0, st, items, scount, np, runrem);
+    MFS_LAUNCH_CHECK();
+    // the partner buffer of the direction vector must be 0 wherever the loop never writes it (a previous solve's liquid)
+    MFS_HIP_TRY(hipMemsetAsync(h->d2, 0, (size_t)h->n * h->c.elt, st));
+    h->skip_items = items; h->skip_runrem = runrem; h->skip_count = scount;
+  }
+  return MFS_OK;
+}
 
 static int jac_begin(mfs_pcg3d* h, double tol, hipStream_t st) {
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;
@@ -581,10 +680,13 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
     h->x_owed = false;
     h->book_pending = false;
     h->slab_loop = false;
+    h->c.live = LiveMap{nullptr, nullptr, 0};
+    h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
     return jac_begin(h, tol, (hipStream_t)stream);
   }
   if (int e = mfs_pcg3d_begin_local(h, tol, stream)) return e;
-  return mfs_pcg3d_begin_finish(h, stream);
+  if (int e = mfs_pcg3d_begin_finish(h, stream)) return e;
+  return pcg_build_live(h, (hipStream_t)stream);      // single-domain solve: the r update sweeps live chunks only
 }
 
 static bool native_fuse_ok(const mfs_pcg3d* h);
@@ -886,6 +988,34 @@ int mfs_pcg3d_loop_info(mfs_pcg3d* h) {
   return ((native_fuse_ok(h) || jf) ? 1 : 0) | (!res && xdef_ok(h) ? 2 : 0) | (h->jacobi ? 4 : 0) | (res ? 8 : 0);
 }
 
+int mfs_pcg3d_set_sparse(mfs_pcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->sparse_vec = on ? 1 : 0;
+  return MFS_OK;
+}
+
+int mfs_pcg3d_sparse_info(mfs_pcg3d* h, mfs_stream stream, int64_t out[4]) {
+  MFS_REQUIRE(h && out, "null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  hipStream_t st = (hipStream_t)stream;
+  int v = 0;
+  if (h->c.live.count) {
+    MFS_HIP_TRY(hipMemcpyAsync(&v, h->c.live.count, sizeof(int), hipMemcpyDeviceToHost, st));
+    MFS_HIP_TRY(hipStreamSynchronize(st));
+    out[0] = v;
+    out[1] = (h->n + kLiveChunk - 1) / kLiveChunk;
+  }
+  if (h->skip_count) {
+    MFS_HIP_TRY(hipMemcpyAsync(&v, h->skip_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    MFS_HIP_TRY(hipStreamSynchronize(st));
+    const int vec = h->dt == MFS_F32 ? 4 : 2;
+    const int64_t ipp = (int64_t)(h->Ny - 2) * (h->Nz / vec);
+    out[2] = v;
+    out[3] = ((ipp + kApplyBlock - 1) / kApplyBlock) * (h->Nx - 2);
+  }
+  return MFS_OK;
+}
+
 // for callers that drive begin / iterate themselves: settles what the loop forms owe (the deferred x update, the
 // direction vector parked in the engine's partner buffer).  Host-synchronous (it needs the iteration count).
 int mfs_pcg3d_finish(mfs_pcg3d* h, mfs_stream stream) {
@@ -1163,6 +1293,8 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
   h->x_owed = false;
   h->book_pending = false;
   h->slab_loop = true;
+  h->c.live = LiveMap{nullptr, nullptr, 0};
+  h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
   ++h->p2p->epoch;
   if (int e = core_begin_pre(h->c, tol, true, st)) return e;            // self.x *= 0.0  (:198)
   int grid = 0;

@@ -91,8 +91,15 @@ __device__ __forceinline__ void stencil_vec(T* __restrict__ out_ptr, vec_t<T, VE
 
 // planes [xb, xe) and, optionally, a second range [xb2, xe2) handled by the same launch
 // (the multi-GPU driver applies its two edge planes {1, L-2} in one launch)
+// items / runrem / count (round 3, optional): the (tile, plane) pairs that compute anything -- every other pair is a tile
+// whose vectors are all ZERO rows with r = d = 0 (air): its q, d and x never change, and the march does not visit it.
+// items[k] = tile * np + plane, ascending; runrem[k] = consecutive items from k on within the tile (one march); *count
+// = how many.  Null: the dense sequence of all pairs.
 struct ApplyArgs {
   int Nx, Ny, Nz, xb, xe, xchunk, xb2, xe2;
+  const int* items = nullptr;
+  const int* runrem = nullptr;
+  const int* count = nullptr;
 };
 
 // ------------------------------------------------------------- variant 0 ----
@@ -332,7 +339,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
   // planes, so all CUs finish together whatever the grid shape; a segment that runs
   // off the end of its tile's x range simply restarts the pipeline on the next tile.
   // `xchunk` > 0 additionally caps the length of one march.
-  const int64_t total = (int64_t)tiles * np;
+  const bool sparse = a.items != nullptr;
+  const int64_t total = sparse ? (int64_t)*a.count : (int64_t)tiles * np;
   const int G = gridDim.x;
   const int nch = min(G, kXcds);
   const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
@@ -346,11 +354,31 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
   const int buf_elems = tile_elems + 2 * Nz;                // one LDS plane image
   double acc = 0.0;
 
+  // BOOK: closing the previous iteration -- at the workgroup's first march (its loads in flight), or after the loop for a
+  // workgroup that has no march at all (sparse work lists can be shorter than the grid)
+  auto close_previous = [&]() -> bool {
+    book_pending = false;
+    __shared__ double s_rr;
+    const double t = block_sum<kBlock>(bk_acc);
+    if (threadIdx.x == 0) s_rr = t;
+    __syncthreads();
+    const double rr = s_rr;                        // == block_total_of(bk.part_rr, bk.npart)
+    // the flag may have been raised by an EARLIER launch, or by workgroup 0 of this one for the very decision every
+    // workgroup takes here: same outcome
+    const bool stop = bk_dn != 0.0 || cg_health(bk_dq, rr) != 0 || rr < bk_tol2;
+    if (bk_dn == 0.0 && blockIdx.x == 0 && threadIdx.x == 0) cg_book(bk.scal, bk.hist, bk.hist_cap, bk.par, bk_dq, rr);
+    src.beta = rr / bk_delta;                      // cg_book's expressions: the values it leaves in S_BETA
+    if (XDEF) alpha_x = bk_delta / bk_dq;          // and S_ALPHA (the step of the iteration being closed)
+    return stop;
+  };
+
   for (int64_t i = s0; i < s1;) {
-    const int tile = (int)(i / np);
-    const int pl = (int)(i - (int64_t)tile * np);          // plane slot inside the (up to two) ranges
+    const int64_t it_ = sparse ? (int64_t)a.items[i] : i;
+    const int tile = (int)(it_ / np);
+    const int pl = (int)(it_ - (int64_t)tile * np);        // plane slot inside the (up to two) ranges
     const int x0 = pl < n1 ? a.xb + pl : a.xb2 + (pl - n1);
     int len = (int)min((int64_t)((pl < n1 ? a.xe : a.xe2) - x0), s1 - i);
+    if (sparse) len = min(len, a.runrem[i]);
     if (a.xchunk > 0) len = min(len, a.xchunk);
     const int x1 = x0 + len;
     i += len;
@@ -378,19 +406,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     const bool h0 = LDS && tid < 2 * nzv;
     if (h0) wh = src.raw((int64_t)x0 * sx + (tid < nzv ? m0 - Nz + tid * VEC : m0 + tile_len + (tid - nzv) * VEC));
     if (BOOK && book_pending) {                      // uniform over the workgroup: its first march
-      book_pending = false;
-      __shared__ double s_rr;
-      const double t = block_sum<kBlock>(bk_acc);
-      if (threadIdx.x == 0) s_rr = t;
-      __syncthreads();
-      const double rr = s_rr;                        // == block_total_of(bk.part_rr, bk.npart)
-      // the flag may have been raised by an EARLIER launch, or by workgroup 0 of this one for the very decision every
-      // workgroup takes here: same outcome
-      const bool stop = bk_dn != 0.0 || cg_health(bk_dq, rr) != 0 || rr < bk_tol2;
-      if (bk_dn == 0.0 && blockIdx.x == 0 && threadIdx.x == 0) cg_book(bk.scal, bk.hist, bk.hist_cap, bk.par, bk_dq, rr);
-      if (stop) return;
-      src.beta = rr / bk_delta;                      // cg_book's expressions: the values it leaves in S_BETA
-      if (XDEF) alpha_x = bk_delta / bk_dq;          // and S_ALPHA (the step of the iteration being closed)
+      if (close_previous()) return;
     }
     vec_t<T, VEC> vm = src.fin(wm), vc = src.fin(wc), vp = src.fin(wp);
     CoefVec<T, VEC> cc = coef_load<T, VEC, COMP, NT, true, ASYM>(diag, cx, cy, cz, base, sx, Nz, cls_c, cz2);
@@ -498,6 +514,9 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       }
     }
     if (LDS) MFS_LDS_BARRIER();  // next work unit reuses buffer 0
+  }
+  if (BOOK && book_pending) {                        // no march in this workgroup: the iteration is closed all the same
+    if (close_previous()) return;
   }
   const double tot = block_sum<kApplyBlock>(acc);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;

@@ -388,7 +388,10 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   const int ipp = (Ny - 2) * nzv;                          // interior z-vectors per plane
   const int tiles = (ipp + BLOCK - 1) / BLOCK;
   const int np = Nx - 2;                                    // planes 1 .. Nx-2
-  const int64_t total = (int64_t)tiles * np;
+  // COMP, work list (the launches of a single-domain CG loop): only the listed (tile, plane) pairs are visited -- every
+  // other pair is all air, its q = +0 was stored by the solve's initial q = A x and nothing else writes it
+  const bool listed = COMP && c.items != nullptr;
+  const int64_t total = listed ? (int64_t)*c.count : (int64_t)tiles * np;
   const int G = gmain;
   const int nch = min(G, 8);
   const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
@@ -398,7 +401,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
   // plane where the whole tile is air costs a fraction of one that computes) -- else the launch lasts as long as the
   // marches that lie entirely in the liquid, however empty the rest of the domain is
   int64_t s0 = total * seg / G, s1 = total * (seg + 1) / G;
-  if (COMP && c.seg_g == G) { s0 = c.seg[seg]; s1 = c.seg[seg + 1]; }
+  if (COMP && !listed && c.seg_g == G) { s0 = c.seg[seg]; s1 = c.seg[seg + 1]; }
   const int64_t su = (int64_t)Ny * Nz, sv = (int64_t)(Ny + 1) * Nz, sw = (int64_t)Ny * W1, sc = c.plane();
   const T* const U = v.p[0];
   const T* const Vv = v.p[1];
@@ -417,10 +420,17 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
 #endif
 
   for (int64_t i = s0; i < s1;) {
-    const int tile = (int)(i / np);
-    const int pl = (int)(i - (int64_t)tile * np);
-    const int x0 = 1 + pl;
-    const int len = (int)min((int64_t)(Nx - 1 - x0), s1 - i);
+    int tile, x0, len;
+    if (listed) {                     // entry = tile * Nx + x; a run of consecutive entries is one march
+      const int it = c.items[i];
+      tile = it / Nx;
+      x0 = it - tile * Nx;
+      len = (int)min((int64_t)c.runrem[i], s1 - i);
+    } else {
+      tile = (int)(i / np);
+      x0 = 1 + (int)(i - (int64_t)tile * np);
+      len = (int)min((int64_t)(Nx - 1 - x0), s1 - i);
+    }
     const int x1 = x0 + len;
     i += len;
     const int item_raw = tile * BLOCK + tid;

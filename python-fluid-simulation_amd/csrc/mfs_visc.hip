@@ -243,6 +243,9 @@ struct Compact {
   int tw_block;
   const int* seg;               // ... and the cost-balanced cut of the (tile, plane) sequence into seg_g segments (k_vcg_balance)
   int seg_g;
+  const int* items;             // work list of the loop's march launches (null: every pair): indices tile * Nx + x of the busy
+  const int* runrem;            // (tile, plane) pairs, ascending; runrem[k] = consecutive entries from k on (one march); *count
+  const int* count;
   const void* bulk;             // ONE value of the state dtype: the largest volume sample of the set-up (what a sub-cell
                                 // deep inside the liquid carries: 1 up to the rounding of lvol / (cell_vol / 8)) -- the
                                 // constant of the compressed class access' second uniform class
@@ -927,6 +930,8 @@ struct mfs_vcg3d {
   int64_t sparse_min;   // ... from this many unknowns on (smaller grids run the resident / merged loops)
   int* live_ws;         // flags | list | count
   bool classes_ready;   // the compressed class access' classes / tile flags / balanced cut match the current set-up
+  int *list_items, *list_runrem, *list_count;      // work list of the loop's march launches (Compact::items), built with the classes
+  bool list_ready;
   int compress;    // 1 (default; MFS_VISC_COMPRESS): the march reads the class arrays only for MIXED vectors (k_vcg_classify)
   int march_nt;    // MFS_VISC_MARCH_NT: nontemporal class loads / q stores (-1 auto by size), read at creation
   int fuse;        // 1: mfs_vcg3d_iterate / solve fold the direction and x updates into the march (2 launches per iteration); default 0
@@ -1076,7 +1081,6 @@ static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* 
 // array-boundary face, a solid face, or all seven volume samples of its row 0 -- and r = d = 0 there at the start of the
 // loop (b - A x0 = 0): then q, r and d stay exactly 0 and x never changes.  A chunk of 1024 unknowns is live when any of
 // its faces is not dead.  Built once per solve (single-domain loops), behind the initial residual.
-constexpr int kLiveChunk = 1024;
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 k_vcg_live_flags(Compact c, const T* __restrict__ r, const T* __restrict__ d, int64_t n, int64_t o1, int64_t o2, int* __restrict__ flags) {
@@ -1111,30 +1115,6 @@ k_vcg_live_flags(Compact c, const T* __restrict__ r, const T* __restrict__ d, in
   }
 }
 
-// flags -> list of live chunk indices + their count (ONE block)
-__global__ void __launch_bounds__(1024)
-k_vcg_live_list(const int* __restrict__ flags, int nchunks, int* __restrict__ list, int* __restrict__ count) {
-  const int t = threadIdx.x;
-  const int per = (nchunks + 1023) / 1024, i0 = min(nchunks, t * per), i1 = min(nchunks, i0 + per);
-  int sum = 0;
-  for (int i = i0; i < i1; ++i) sum += flags[i] != 0;
-  __shared__ int s_pre[1024];
-  s_pre[t] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = t >= o ? s_pre[t - o] : 0;
-    __syncthreads();
-    s_pre[t] += v;
-    __syncthreads();
-  }
-  int run = s_pre[t] - sum;
-  for (int i = i0; i < i1; ++i)
-    if (flags[i] != 0) list[run++] = i;
-  if (t == 1023) *count = s_pre[1023];
-}
-
-static size_t live_ws_bytes(int64_t n) { return align_up((size_t)(2 * ((n + kLiveChunk - 1) / kLiveChunk) + 64) * sizeof(int), 4096); }
-
 // (a wave marks the chunks of ALL its 64 vectors live when any of them is: conservative, never wrong)
 static int vcg_build_live(mfs_vcg3d* h, hipStream_t st) {
   h->c.live = LiveMap{nullptr, nullptr, 0};
@@ -1150,7 +1130,7 @@ static int vcg_build_live(mfs_vcg3d* h, hipStream_t st) {
     hipLaunchKernelGGL((k_vcg_live_flags<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, (const float*)h->c.r, (const float*)h->c.d, h->n, h->off[1], h->off[2], flags);
   else
     hipLaunchKernelGGL((k_vcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, (const double*)h->c.r, (const double*)h->c.d, h->n, h->off[1], h->off[2], flags);
-  hipLaunchKernelGGL(k_vcg_live_list, dim3(1), dim3(1024), 0, st, flags, nchunks, list, count);
+  hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, flags, nchunks, list, count);
   MFS_LAUNCH_CHECK();
   int shift = 0;
   while ((1 << shift) < kLiveChunk / vec) ++shift;
@@ -1164,6 +1144,7 @@ static int vcg_build_classes(mfs_vcg3d* h, hipStream_t stream) {
   const int Nx = h->g.N[0], Ny = h->g.N[1], Nz = h->g.N[2];
   unsigned char* mp = (unsigned char*)h->cp.msk;
   h->classes_ready = true;
+  h->list_ready = false;
   h->cp.tw_block = 0;
   h->cp.seg_g = 0;
   if (Nx >= 3 && Ny >= 3) {    // classes of the interior z-vectors for the march's compressed class access
@@ -1200,6 +1181,14 @@ static int vcg_build_classes(mfs_vcg3d* h, hipStream_t stream) {
           hipLaunchKernelGGL(k_vcg_balance, dim3(1), dim3(1024), 0, stream, flags, tiles, Nx, G, (int*)h->cp.seg);
           MFS_LAUNCH_CHECK();
           h->cp.seg_g = G;
+        }
+        // the work list of the CG loop's launches: the busy pairs only (an all-air pair's q is +0 and stays what the
+        // initial q = A x stored there)
+        if (nt < 0x7fffffff) {
+          hipLaunchKernelGGL(k_live_list<unsigned char>, dim3(1), dim3(1024), 0, stream, flags, (int)nt, h->list_items, h->list_count);
+          hipLaunchKernelGGL(k_list_runs, dim3(cdiv(nt, 256)), dim3(256), 0, stream, h->list_items, h->list_count, Nx, h->list_runrem);
+          MFS_LAUNCH_CHECK();
+          h->list_ready = true;
         }
       }
     }
@@ -1653,9 +1642,10 @@ size_t mfs_vcg3d_workspace_bytes(const int64_t gres[3], int dt) {
   tot += align_up((size_t)kMaxPartials * 8, 4096);                        // r.z partials (Jacobi loop)
   tot += vres_ws_bytes(mfs_vcg3d_dofs(gres), dtype_size(dt));             // resident loop: records + face mirror (0 if too big)
   tot += 4096;                                                            // the bulk volume value (compressed class access)
-  tot += live_ws_bytes(mfs_vcg3d_dofs(gres));                             // live chunks of the flat vectors
+  tot += core_live_ws_bytes(mfs_vcg3d_dofs(gres));                             // live chunks of the flat vectors
   tot += tile_words_bytes(gres, dt);                                      // its tile words
   tot += align_up((size_t)(kVmMaxSegs + 1) * sizeof(int), 4096);          // ... and the cost-balanced segment starts
+  tot += 2 * tile_words_bytes(gres, dt) * sizeof(int) + 4096;             // ... and the work list of the loop's launches
   return tot;
 }
 
@@ -1695,6 +1685,11 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->cp.tw_block = 0;
   h->cp.seg = (const int*)p; p += align_up((size_t)(kVmMaxSegs + 1) * sizeof(int), 4096);
   h->cp.seg_g = 0;
+  h->cp.items = nullptr; h->cp.runrem = nullptr; h->cp.count = nullptr;
+  h->list_items = (int*)p; p += tile_words_bytes(gres, dt) * sizeof(int);
+  h->list_runrem = (int*)p; p += tile_words_bytes(gres, dt) * sizeof(int);
+  h->list_count = (int*)p; p += 4096;
+  h->list_ready = false;
   h->resident = env_int("MFS_VISC_RESIDENT", -1);
   h->res = VResPlan{};
   h->res_ar = nullptr; h->res_mirror = nullptr; h->res_epoch = 0;
@@ -1721,7 +1716,7 @@ int mfs_vcg3d_create(mfs_vcg3d** out, const int64_t gres[3], int dt, void* works
   h->classes_ready = false;
   h->sparse_vec = env_int("MFS_VISC_SPARSE", 1);
   h->sparse_min = (int64_t)env_int("MFS_VISC_SPARSE_MIN", 1 << 21);
-  h->live_ws = (int*)p; p += live_ws_bytes(h->n);
+  h->live_ws = (int*)p; p += core_live_ws_bytes(h->n);
   h->march_nt = env_int("MFS_VISC_MARCH_NT", -1);
   h->fuse = env_int("MFS_VISC_FUSE", 0);   // measured slower than the three-launch loop: opt-in
   h->fused_run = false;
@@ -2101,6 +2096,13 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   // small problems: both vector phases, the r.r reduction and the bookkeeping in ONE launch whose workgroups exchange
   // their partial sums while resident (k_update_rdx, mfs_cg_core.h): 2 launches per iteration, no reduction tail
   const bool rdx = core_rdx_ok(h->c) && !h->p2p;
+  // single-domain solves with live-chunk vector phases (vcg_build_live): the march visits only the busy (tile, plane)
+  // pairs -- q of an all-air pair is +0 since the initial q = A x and nothing else writes it
+  if (h->c.live.list && h->compress && !h->mask_cg) {
+    if (!h->classes_ready) { if (int e = vcg_build_classes(h, st)) return e; }
+    if (h->list_ready) { h->cp.items = h->list_items; h->cp.runrem = h->list_runrem; h->cp.count = h->list_count; }
+  }
+  struct ListOff { mfs_vcg3d* h; ~ListOff() { h->cp.items = nullptr; h->cp.runrem = nullptr; h->cp.count = nullptr; } } list_off{h};
   for (int64_t i = 0; i < n; ++i) {
     int e, np = 0;
     if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;   // :589

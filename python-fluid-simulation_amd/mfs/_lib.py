@@ -91,6 +91,8 @@ SIGNATURES = {
     "mfs_pcg3d_scalars": (_p, [_p]),
     "mfs_pcg3d_tune": (_i, [_p, _i, _i, _i, _i]),
     "mfs_pcg3d_loop_info": (_i, [_p]),
+    "mfs_pcg3d_set_sparse": (_i, [_p, _i]),
+    "mfs_pcg3d_sparse_info": (_i, [_p, _p, _pi64]),
     "mfs_pcg3d_set_jacobi": (_i, [_p, _i]),
     "mfs_pcg3d_set_defer_x": (_i, [_p, _i]),
     "mfs_pcg3d_set_lean": (_i, [_p, _i]),

@@ -249,8 +249,11 @@ class SlabCG(_BoundedCollectives):
             self._note_downgrade()
             self.multi = True                  # a window was given but cannot be used: the collective loop
         if not self.multi:
-            self.ops.begin_local(tol)
-            self.ops.begin_finish()
+            if hasattr(self.ops, "begin"):
+                self.ops.begin(tol)            # the engine's single-domain entry point (it also builds the solve's sparse lists)
+            else:
+                self.ops.begin_local(tol)
+                self.ops.begin_finish()
             return
         self._drop_jacobi()
         self.ops.begin_local(tol)              # x = 0 everywhere, so q = A x needs no halo

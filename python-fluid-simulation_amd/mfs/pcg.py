@@ -57,6 +57,16 @@ class PcgEngine:
         return dict(fused_direction_update=bool(b & 1), deferred_x_update=bool(b & 2), jacobi=bool(b & 4),
                     resident=bool(b & 8))
 
+    def set_sparse(self, on):
+        """single-domain solves from 2 M cells: live-chunk r update + sparse work list of the fused stencil launches"""
+        _lib.check(self.lib.mfs_pcg3d_set_sparse(self.h, int(bool(on))), "mfs_pcg3d_set_sparse")
+
+    def sparse_info(self):
+        import ctypes
+        out = (ctypes.c_int64 * 4)()
+        _lib.check(self.lib.mfs_pcg3d_sparse_info(self.h, T.stream(), out), "mfs_pcg3d_sparse_info")
+        return dict(live_chunks=int(out[0]), chunks=int(out[1]), listed_pairs=int(out[2]), pairs=int(out[3]))
+
     def set_resident(self, on):
         """small grids: run each batch of iterations as one resident launch (None = auto: whenever the grid fits)"""
         _lib.check(self.lib.mfs_pcg3d_set_resident(self.h, -1 if on is None else int(bool(on))), "mfs_pcg3d_set_resident")

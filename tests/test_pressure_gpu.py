@@ -332,3 +332,77 @@ def test_fused_direction_update_is_bit_identical(mods, name, prec):
     for i in (2, 3, 4, 5):
         assert torch.equal(a[i], b[i]), i          # x, d (brought home from the partner buffer), r, q
     assert all(torch.equal(p_, q_) for p_, q_ in zip(a[6], b[6]))
+
+
+# ------------------------------------------------------------------ sparse work list + live chunks (round 3) ----------
+def _blob_problem(gres, centre, radius, seed):
+    """a ball of liquid in an otherwise empty box (most tiles of the march are air): lphi, unit weights with a few
+    quarter weights inside, a random right-hand side in the liquid"""
+    dev = DEV
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ax = [torch.arange(n, device=dev, dtype=torch.float64) + 0.5 for n in gres]
+    X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+    lphi = torch.sqrt((X - centre[0]) ** 2 + (Y - centre[1]) ** 2 + (Z - centre[2]) ** 2) - radius
+    def w(shape):
+        q = torch.randint(1, 5, shape, generator=g, device=dev).double() * 0.25
+        return torch.where(torch.rand(shape, generator=g, device=dev) < 0.9, torch.ones(shape, dtype=torch.float64, device=dev), q)
+    wx, wy, wz = w((gres[0] + 1, gres[1], gres[2])), w((gres[0], gres[1] + 1, gres[2])), w((gres[0], gres[1], gres[2] + 1))
+    b = torch.randn(gres, generator=g, device=dev, dtype=torch.float64) * (lphi < 0)
+    b[0] = 0; b[-1] = 0; b[:, 0] = 0; b[:, -1] = 0; b[:, :, 0] = 0; b[:, :, -1] = 0
+    return lphi, wx, wy, wz, b
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_sparse_work_list_and_live_chunks_match_the_dense_loop(dt, monkeypatch):
+    """round 3: behind the initial residual a single-domain solve lists the (tile, plane) pairs of the march that compute
+    anything and the 1024-cell chunks that hold a live unknown; the fused stencil launches and the r update visit only
+    those.  A ball of liquid in a 160 x 96 x 128 box (2 M cells: the size from which the lists are built) -- and then, THROUGH
+    THE SAME ENGINE, a ball elsewhere (the partner buffer of the direction vector still holds the first solve's liquid) --
+    against the engine with the lists off: same history to rounding (dot products group differently), same solution."""
+    from mfs.pcg import PcgEngine
+    gres = (160, 96, 128)
+    outs = {}
+    for sparse in ("1", "0"):
+        monkeypatch.setenv("MFS_SPARSE", sparse)
+        eng = PcgEngine(gres, dt, DEV)
+        res = []
+        for centre, radius, seed in (((50.0, 40.0, 60.0), 22.0, 1), ((110.0, 60.0, 50.0), 18.0, 2)):
+            lphi, wx, wy, wz, b = _blob_problem(gres, centre, radius, seed)
+            eng.setup(lphi.to(dt), wx.to(dt), wy.to(dt), wz.to(dt))
+            bt = b.to(dt)
+            x, d, r, q = (torch.zeros(gres, dtype=dt, device=DEV) for _ in range(4))
+            q[1:-1, 1:-1, 1:-1] = 5.0                  # stale q: begin must overwrite every computed cell
+            eng.bind(bt, x, d, r, q)
+            ok, it = eng.solve(1e-6 if dt == torch.float64 else 1e-3, 4000, 16)
+            torch.cuda.synchronize()
+            assert ok
+            res.append((it, np.asarray(eng.history()), x.clone(), q.clone()))
+        outs[sparse] = res
+    for (it_s, h_s, x_s, q_s), (it_d, h_d, x_d, q_d) in zip(outs["1"], outs["0"]):
+        assert abs(it_s - it_d) <= 1, (it_s, it_d)
+        n = min(len(h_s), len(h_d), 41)
+        np.testing.assert_allclose(h_s[:n], h_d[:n], rtol=1e-10 if dt == torch.float64 else 1e-4)
+        tol = 1e-8 if dt == torch.float64 else 1e-3
+        assert float((x_s - x_d).abs().max()) <= tol * float(x_d.abs().max())
+        air = x_d == 0
+        assert torch.equal(x_s[air], x_d[air])         # nothing leaks into the air
+
+
+def test_sparse_lists_are_off_for_small_grids_and_on_from_two_million_cells():
+    from mfs.pcg import PcgEngine
+    for gres, on in (((24, 20, 16), False), ((160, 96, 144), True)):
+        lphi, wx, wy, wz, b = _blob_problem(gres, (12.0, 10.0, 8.0), 6.0, 3)
+        eng = PcgEngine(gres, torch.float64, DEV)
+        eng.setup(lphi, wx, wy, wz)
+        x, d, r, q = (torch.zeros(gres, dtype=torch.float64, device=DEV) for _ in range(4))
+        eng.bind(b, x, d, r, q)
+        ok, it = eng.solve(1e-8, 2000, 8)
+        assert ok and it > 0
+        info = eng.sparse_info()
+        if not on:
+            assert info == dict(live_chunks=0, chunks=0, listed_pairs=0, pairs=0), info
+            continue
+        assert 0 < info["live_chunks"] < info["chunks"] // 20 and 0 < info["listed_pairs"] < info["pairs"] // 20, info
+        eng.set_sparse(False)
+        eng.begin(1e-8)
+        assert eng.sparse_info()["pairs"] == 0
