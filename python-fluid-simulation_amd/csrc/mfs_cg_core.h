@@ -1037,7 +1037,9 @@ struct CgCore {
   unsigned long long rdx_timeout_ticks = 25000000ull;   // MFS_RDX_TIMEOUT_MS (wall clock, 100 MHz)
   int rdx_drop_wg = -1;                                 // MFS_RDX_TEST_DROP_WG: fault injection, tests only
   int nt_q = -1, nt_rd = -1;                            // MFS_NT_Q, MFS_NT_RD (A/B: -1 auto by size)
-  LiveMap live{nullptr, nullptr, 0};                    // live chunks of the bound vectors (viscosity, single domain); null: all
+  LiveMap live{nullptr, nullptr, 0};                    // live chunks of the bound vectors (single domain / a slab's owned planes); null: all
+  int64_t live_off = 0, live_cnt = -1;                  // ... built over the elements [live_off, live_off + live_cnt): only a sweep of
+                                                        // exactly that range takes the list (-1: the whole vectors)
 };
 
 static inline size_t core_ws_bytes() {
@@ -1118,7 +1120,7 @@ static inline int core_reduce(CgCore& c, int which, int check_done, hipStream_t 
 #define MFS_XR(TT, VV, NN, MM) \
   hipLaunchKernelGGL((k_update_xr<TT, VV, NN, MM>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.x + off, (const TT*)dsrc + off, \
                      (TT*)c.r + off, (const TT*)c.q + off, cnt, c.scal, c.part_rr, c.rev_xr, (int)(c.iter_enq & 1), \
-                     c.part_dq, fold ? c.n_part_dq : 0, tl, pdv, (off == 0 && cnt == c.n) ? c.live : LiveMap{nullptr, nullptr, 0})
+                     c.part_dq, fold ? c.n_part_dq : 0, tl, pdv, (off == c.live_off && cnt == (c.live_cnt < 0 ? c.n : c.live_cnt)) ? c.live : LiveMap{nullptr, nullptr, 0})
 #define MFS_XR_MODE(MM)                                                                                              \
   if (c.dt == MFS_F32) {                                                                                             \
     if (!vec) MFS_XR(float, 1, false, MM); else if (ntx) MFS_XR(float, 4, true, MM); else MFS_XR(float, 4, false, MM); \
@@ -1171,7 +1173,7 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
 #define MFS_UD(TT, VV, NN) \
     hipLaunchKernelGGL((k_update_d<TT, VV, true, NN>), dim3(grid), dim3(kBlock), 0, st, (TT*)c.d, (const TT*)c.r, c.n, c.scal, \
                        c.hist, kHistCap, rev_d, (int)(c.iter_enq & 1), c.part_rr, fold ? c.n_part_rr : 0, (TT*)c.x, nt_r, \
-                       -(double)(c.iter_enq + 1), c.live)
+                       -(double)(c.iter_enq + 1), (c.live_off == 0 && (c.live_cnt < 0 || c.live_cnt == c.n)) ? c.live : LiveMap{nullptr, nullptr, 0})
     const int rev_d = c.rev_d;
     // ... and so is r here (same-engine A/B: viscosity 256^3 632.8 -> 596.6 us/iteration, 192^3 250.0 -> 243.6)
     const int nt_r_knob = c.nt_rd;

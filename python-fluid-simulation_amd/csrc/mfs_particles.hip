@@ -378,13 +378,6 @@ k_p2g_scatter_tiled(PGrid g, PGeom geo, PTiles pt, int axis, const void* px, int
   }
 }
 
-// LDS twin of atomic_min_t for doubles (plain read first; integer min / max on the bit pattern, see atomic_min_t)
-__device__ __forceinline__ void lds_min_f64(double* a, double v) {
-  if (*a <= v) return;
-  if (v >= 0.0) atomicMin(reinterpret_cast<long long*>(a), __double_as_longlong(v));
-  else atomicMax(reinterpret_cast<unsigned long long*>(a), (unsigned long long)__double_as_longlong(v));
-}
-
 // compute_fls_kernel, one workgroup per tile: cells [c0 - 2, c0 + kTB + 1] per axis staged
 __global__ void __launch_bounds__(256)
 k_fluid_levelset_tiled(PGrid g, PGeom geo, PTiles pt, double r, const void* px, int pxdt, const int* __restrict__ perm,
@@ -430,12 +423,11 @@ k_fluid_levelset_tiled(PGrid g, PGeom geo, PTiles pt, double r, const void* px, 
           const double n = nxy + sq[2][a2];
           const int l = (lxy | lo[2][a2]) < 0 ? -1 : lxy + lo[2][a2];
           if (l >= 0) {
-            // sqrt(n) - r < cur  <=>  n < (cur + r)^2 (cur + r > 0): tested on the squares first, with a margin of 1e-12
-            // for their rounding -- once the tile has settled almost every candidate loses here, without the fp64 square
-            // root (125 per particle).  A candidate that passes is evaluated exactly.
-            const double lim = lp[l] + r;
-            if (lim <= 0.0 || n * (1.0 - 1e-12) >= lim * lim) continue;
-            lds_min_f64(&lp[l], sqrt(n) - r);
+            // the staged table holds the minimum of the SQUARED distance: n -> sqrt(n) - r is monotone (a correctly rounded
+            // square root and a rounded subtraction of a constant both are), so sqrt(min n) - r, formed once per node below,
+            // IS min(sqrt(n) - r) bit for bit -- and the 125 candidates of a particle cost an add, an LDS read and a
+            // compare each instead of an fp64 square root.  n >= +0: its bit pattern orders like the value.
+            if (n < lp[l]) atomicMin(reinterpret_cast<unsigned long long*>(&lp[l]), (unsigned long long)__double_as_longlong(n));
           } else {
             atomic_min_t(phi, phidt, g.at(ci[0][a0], ci[1][a1], ci[2][a2]), sqrt(n) - r, false);
           }
@@ -447,7 +439,7 @@ k_fluid_levelset_tiled(PGrid g, PGeom geo, PTiles pt, double r, const void* px, 
     const double v = lp[l];
     if (v == kInf) continue;
     const int lz = l % E, ly = (l / E) % E, lx = l / (E * E);
-    atomic_min_t(phi, phidt, g.at(o[0] + lx, o[1] + ly, o[2] + lz), v, false);
+    atomic_min_t(phi, phidt, g.at(o[0] + lx, o[1] + ly, o[2] + lz), sqrt(v) - r, false);
   }
 }
 

@@ -116,6 +116,7 @@ struct mfs_pcg3d {
   hipStream_t aux;
   hipEvent_t ev_main, ev_aux;
   const int *skip_items, *skip_runrem, *skip_count;   // sparse work list of the fused stencil launches (null: dense), per solve
+  int skip_xb, skip_xe;        // ... built for the launch over the planes [skip_xb, skip_xe)
   int* skip_ws;                // tile flags | items | runrem | count
   int sparse_vec;              // 1 (default; MFS_SPARSE): the r update of a single-domain solve sweeps live chunks only (LiveMap)
   int64_t sparse_min;          // ... from this many cells on
@@ -147,7 +148,7 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
   ApplyArgs a{h->Nx, h->Ny, h->Nz, xb, xe, xchunk, xb2, xe2};
   // sparse work list (built behind the initial residual of a single-domain solve): the fused launches of the loop visit
   // only (tile, plane) pairs that compute anything.  The launch's range must be the list's: all computed planes, one range.
-  if (fz && h->skip_items && h->compress != 0 && VEC > 1 && xb == 1 && xe == h->Nx - 1 && xe2 == xb2 && variant >= 2) {
+  if (fz && h->skip_items && h->compress != 0 && VEC > 1 && xb == h->skip_xb && xe == h->skip_xe && xe2 == xb2 && variant >= 2) {
     a.items = h->skip_items; a.runrem = h->skip_runrem; a.count = h->skip_count;
   }
   const int np = (xe - xb) + (xe2 - xb2);
@@ -570,7 +571,8 @@ static bool native_fuse_ok(const mfs_pcg3d* h);
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 k_pcg_live_flags(const unsigned char* __restrict__ cls, const T* __restrict__ r, const T* __restrict__ d, int64_t n, int* __restrict__ flags,
-                 int Nx, int Ny, int nzv, int* __restrict__ tflags) {
+                 int x_first, int Ny, int nzv, int xb, int xe, int* __restrict__ tflags) {
+  // cls, r, d start at plane x_first of the arrays; n elements from there; the march's planes are [xb, xe)
   const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i0 = iv * VEC;
   bool live = false;
@@ -579,8 +581,8 @@ k_pcg_live_flags(const unsigned char* __restrict__ cls, const T* __restrict__ r,
 #pragma unroll
     for (int j = 0; j < VEC; ++j) live = live || r[i0 + j] != (T)0 || d[i0 + j] != (T)0;
     if (live && tflags) {      // ... and the march's (tile, plane) pair of this vector (interior vectors only: the others are never computed)
-      const int zv = (int)(iv % nzv), y = (int)((iv / nzv) % Ny), x = (int)(iv / ((int64_t)nzv * Ny));
-      if (x >= 1 && x <= Nx - 2 && y >= 1 && y <= Ny - 2) tflags[(int64_t)(((y - 1) * nzv + zv) / kApplyBlock) * (Nx - 2) + (x - 1)] = 1;
+      const int zv = (int)(iv % nzv), y = (int)((iv / nzv) % Ny), x = x_first + (int)(iv / ((int64_t)nzv * Ny));
+      if (x >= xb && x < xe && y >= 1 && y <= Ny - 2) tflags[(int64_t)(((y - 1) * nzv + zv) / kApplyBlock) * (xe - xb) + (x - xb)] = 1;
     }
   }
   if (__builtin_amdgcn_ballot_w64(live) != 0 && (threadIdx.x & 63) == 0) {
@@ -590,40 +592,51 @@ k_pcg_live_flags(const unsigned char* __restrict__ cls, const T* __restrict__ r,
   }
 }
 
-static int pcg_build_live(mfs_pcg3d* h, hipStream_t st) {
+// slab: the window / collective slab loops -- the vector phases cover the owned planes [1, Nx-1), the fused interior launch
+// the planes [2, Nx-2) that touch no ghost (the edge planes have their own dense launches).  A vector's liveness is a
+// property of its own rank: a ZERO row gives q = 0 whatever its neighbours -- ghost planes included -- hold.
+static int pcg_build_live(mfs_pcg3d* h, hipStream_t st, bool slab = false) {
   h->c.live = LiveMap{nullptr, nullptr, 0};
+  h->c.live_off = 0; h->c.live_cnt = h->n;
   h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
   if (!h->sparse_vec || !h->compress || !h->vec_ok || !core_vec_ok(h->c) || h->n < h->sparse_min || h->jacobi) return MFS_OK;
   const int vec = h->dt == MFS_F32 ? 4 : 2;
-  const int nchunks = (int)((h->n + kLiveChunk - 1) / kLiveChunk);
+  const int64_t plane_elems = (int64_t)h->Ny * h->Nz;
+  if (slab && h->Nx < 3) return MFS_OK;
+  const int x_first = slab ? 1 : 0;
+  const int64_t off = slab ? plane_elems : 0, cnt = slab ? plane_elems * (h->Nx - 2) : h->n;
+  const int nchunks = (int)((cnt + kLiveChunk - 1) / kLiveChunk);
   int* flags = h->live_ws;
   int* list = flags + nchunks;
   int* count = list + nchunks;
   MFS_HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nchunks * sizeof(int), st));
   // the fused stencil launches' work list: (tile, plane) pairs with a live vector, tile-major
-  const int nzv = h->Nz / vec, np = h->Nx - 2;
+  const int xb = slab ? 2 : 1, xe = slab ? h->Nx - 2 : h->Nx - 1;
+  const int nzv = h->Nz / vec, np = xe - xb;
   const int64_t ipp = (int64_t)(h->Ny - 2) * nzv;
   const int tiles = (int)((ipp + kApplyBlock - 1) / kApplyBlock);
   const int64_t gr[3] = {h->Nx, h->Ny, h->Nz};
   const int64_t npairs = (int64_t)tiles * np;
-  const bool skip = h->Nx >= 3 && h->Ny >= 3 && npairs > 0 && npairs <= skip_pairs(gr, h->dt) && npairs < 0x7fffffff && native_fuse_ok(h);
+  const bool skip = h->Nx >= 3 && h->Ny >= 3 && np > 0 && npairs > 0 && npairs <= skip_pairs(gr, h->dt) && npairs < 0x7fffffff &&
+                    (slab || native_fuse_ok(h));
   int* tflags = h->skip_ws;
   int* items = tflags + npairs;
   int* runrem = items + npairs;
   int* scount = runrem + npairs;
   if (skip) MFS_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)npairs * sizeof(int), st));
-  const int64_t nvec = h->n / vec;
+  const int64_t nvec = cnt / vec;
   if (h->dt == MFS_F32)
-    hipLaunchKernelGGL((k_pcg_live_flags<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls, (const float*)h->c.r, (const float*)h->c.d, h->n, flags,
-                       h->Nx, h->Ny, nzv, skip ? tflags : (int*)nullptr);
+    hipLaunchKernelGGL((k_pcg_live_flags<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls + off / vec, (const float*)h->c.r + off,
+                       (const float*)h->c.d + off, cnt, flags, x_first, h->Ny, nzv, xb, xe, skip ? tflags : (int*)nullptr);
   else
-    hipLaunchKernelGGL((k_pcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls, (const double*)h->c.r, (const double*)h->c.d, h->n, flags,
-                       h->Nx, h->Ny, nzv, skip ? tflags : (int*)nullptr);
+    hipLaunchKernelGGL((k_pcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls + off / vec, (const double*)h->c.r + off,
+                       (const double*)h->c.d + off, cnt, flags, x_first, h->Ny, nzv, xb, xe, skip ? tflags : (int*)nullptr);
   hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, flags, nchunks, list, count);
   MFS_LAUNCH_CHECK();
   int shift = 0;
   while ((1 << shift) < kLiveChunk / vec) ++shift;
   h->c.live = LiveMap{list, count, shift};
+  h->c.live_off = off; h->c.live_cnt = cnt;
   if (skip) {
     hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, tflags, (int)npairs, items, scount);
     hipLaunchKernelGGL(k_list_runs, dim3(cdiv(npairs, 256)), dim3(256), 0, st, items, scount, np, runrem);
@@ -631,6 +644,7 @@ static int pcg_build_live(mfs_pcg3d* h, hipStream_t st) {
     // the partner buffer of the direction vector must be 0 wherever the loop never writes it (a previous solve's liquid)
     MFS_HIP_TRY(hipMemsetAsync(h->d2, 0, (size_t)h->n * h->c.elt, st));
     h->skip_items = items; h->skip_runrem = runrem; h->skip_count = scount;
+    h->skip_xb = xb; h->skip_xe = xe;
   }
   return MFS_OK;
 }
@@ -1003,7 +1017,7 @@ int mfs_pcg3d_sparse_info(mfs_pcg3d* h, mfs_stream stream, int64_t out[4]) {
     MFS_HIP_TRY(hipMemcpyAsync(&v, h->c.live.count, sizeof(int), hipMemcpyDeviceToHost, st));
     MFS_HIP_TRY(hipStreamSynchronize(st));
     out[0] = v;
-    out[1] = (h->n + kLiveChunk - 1) / kLiveChunk;
+    out[1] = ((h->c.live_cnt < 0 ? h->n : h->c.live_cnt) + kLiveChunk - 1) / kLiveChunk;
   }
   if (h->skip_count) {
     MFS_HIP_TRY(hipMemcpyAsync(&v, h->skip_count, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1011,7 +1025,7 @@ int mfs_pcg3d_sparse_info(mfs_pcg3d* h, mfs_stream stream, int64_t out[4]) {
     const int vec = h->dt == MFS_F32 ? 4 : 2;
     const int64_t ipp = (int64_t)(h->Ny - 2) * (h->Nz / vec);
     out[2] = v;
-    out[3] = ((ipp + kApplyBlock - 1) / kApplyBlock) * (h->Nx - 2);
+    out[3] = ((ipp + kApplyBlock - 1) / kApplyBlock) * (h->skip_xe - h->skip_xb);
   }
   return MFS_OK;
 }
@@ -1322,7 +1336,8 @@ int mfs_pcg3d_slab_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
                      h->p2p->dev, 0, slab_ar_tag(h->p2p, 0));
   MFS_LAUNCH_CHECK();
   if (h->rccl) { if (int e = rccl_sum(h->rccl, h->c.scal + S_RR, 1, st)) return e; }      // (the window is this rank's own)
-  return core_begin_finish(h->c, st);
+  if (int e = core_begin_finish(h->c, st)) return e;
+  return pcg_build_live(h, st, true);
 }
 
 int mfs_pcg3d_slab_iterate(mfs_pcg3d* h, int64_t n, mfs_stream stream) {

@@ -122,6 +122,37 @@ def test_slab_p2p_deferred_x_update(name, world, tmp_path):
     np.testing.assert_array_equal(out["0"][1], out["1"][1])
 
 
+@pytest.mark.parametrize("name,world,dtname", [("p3d_d_20", 2, "f64"), ("p3d_f_40x36x32_sv", 2, "f64"), ("p3d_d_20", 3, "f32"),
+                                               ("p3d_a_12", 5, "f64"), ("p3d_f_40x36x32_sv", 1, "f64")])
+def test_slab_p2p_sparse_lists(name, world, dtname, tmp_path):
+    """round 3: the slab loops build the solve's sparse lists too (live chunks of the owned planes for the r update, the
+    (tile, plane) pairs of the interior launch that hold a live vector) -- forced onto these small grids with
+    MFS_SPARSE_MIN=1, two solves through the same engines (deferred x update and second stream on), against the same
+    loops with the lists off: same history to rounding (the dot products group differently), same solution."""
+    require_default_engine("test_slab_p2p_sparse_lists")
+    g = golden(name)
+    gres = tuple(int(v) for v in g["gres"])
+    out = {}
+    for sparse in ("1", "0"):
+        res = _run_ranks(name, world, tmp_path, dtname, solves=2, MFS_SPARSE=sparse, MFS_SPARSE_MIN="1", MFS_DEFER_X="1",
+                         MFS_SLAB_AUX_STREAM="1")
+        x = np.zeros(gres)
+        for r in res:
+            assert int(r["done"]) == 1
+            lo, hi = int(r["lo"]), int(r["hi"])
+            x[lo + 1:hi - 1] = r["x"][1:-1]
+        for r in res[1:]:
+            np.testing.assert_array_equal(r["hist"], res[0]["hist"])
+        out[sparse] = (res[0]["hist"], x, int(res[0]["iters"]))
+    (h1, x1, it1), (h0, x0, it0) = out["1"], out["0"]
+    assert abs(it1 - it0) <= max(2, it0 // 10)
+    n = min(21 if dtname == "f64" else 17, len(h1), len(h0))
+    np.testing.assert_allclose(h1[:n], h0[:n], rtol=1e-10 if dtname == "f64" else 1e-5)
+    np.testing.assert_allclose(x1, x0, rtol=0, atol=(1e-4 if dtname == "f64" else 1e-3) * np.abs(x0).max())
+    air = x0 == 0
+    np.testing.assert_array_equal(x1[air], 0.0)
+
+
 @pytest.mark.parametrize("name,world", [("p3d_d_20", 2), ("p3d_b_10x12x14_sv", 2), ("p3d_d_20", 3)])
 def test_slab_solver_class_matches_reference_outputs(name, world, tmp_path):
     """SlabPressureCGSolver3D.solve (the reference's solve signature on a rank's slab): RHS, pressure and the
