@@ -331,6 +331,22 @@ def viscosity_leg(torch, dev, n, steps, with_parity, precision="fp32", ev_over=0
     out.update({"us_per_iteration": round(dt / steps * 1e6, 2), "Mcells_per_s": round(cells * steps / dt / 1e6, 1)})
     if e.apply_kernel() == "march":
         out["class_census"] = e.class_census()
+    sp = e.sparse_info()
+    if sp["chunks"]:
+        # the same loop with the solve's sparse lists off (same process): what they are worth on this scene
+        e.set_sparse(False)
+        e.begin(0.0)
+        e.iterate(10)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e.iterate(steps)
+        torch.cuda.synchronize()
+        out["sparse_lists"] = dict(sp, us_per_iteration_lists_off=round((time.perf_counter() - t1) / steps * 1e6, 2),
+                                   note="live 32-unknown chunks for the r and d / x updates, busy (tile, plane) pairs for the loop's march "
+                                        "launches; the `apply` legs below time the stand-alone launch, which visits every pair")
+        e.set_sparse(True)
+        e.begin(0.0)
+        e.iterate(2)
     if cells >= 64 ** 3:
         # the apply launch inside real iterations (phase form of the same kernels: the events bracket one launch each)
         reps = 24
@@ -980,7 +996,7 @@ def main():
             ms_dense_apply = time_apply(eng, reps_leg, robust=True)
             eng.set_sparse(True)
             sparse_line = dict(sp, ms_per_step_lists_off=round(ms_dense_loop, 5), stencil_launch_ms_lists_off=round(ms_dense_apply, 5),
-                               note="single-domain solves from 2^21 cells: live 1024-cell chunks for the r update, listed (tile, plane) "
+                               note="single-domain solves from 2^21 cells: live 32-cell chunks for the r update, listed (tile, plane) "
                                     "pairs for the fused stencil launches; dead cells keep q = r = d = 0 and x as the dense loop leaves them")
         # the PLAIN stencil apply (6N^3 + 3N^2 scalars -- the figure BASELINE.md's 60 % target is
         # stated on), inside the three-kernel form of the loop (direction update unfused)

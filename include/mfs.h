@@ -200,7 +200,7 @@ int mfs_pcg3d_set_compress(mfs_pcg3d* h, int on);
  * bit 1 = x update deferred into it too, bit 2 = Jacobi loop, bit 3 = resident small-grid loop (mfs_pcg3d_set_resident) */
 int mfs_pcg3d_loop_info(mfs_pcg3d* h);
 /* sparse lists of a single-domain solve (round 3; default on from 2^21 cells, env MFS_SPARSE / MFS_SPARSE_MIN): behind the
- * initial residual mfs_pcg3d_begin lists the 1024-cell chunks holding a live z-vector (row not ZERO, or r, d != 0) and the
+ * initial residual mfs_pcg3d_begin lists the 32-cell chunks holding a live z-vector (row not ZERO, or r, d != 0) and the
  * (tile, plane) pairs of the march holding one; the r update sweeps the listed chunks, the fused stencil launches visit the
  * listed pairs.  Dead vectors keep q = r = d = +0 and x unchanged, which is what the dense loop computes for them; the dot
  * products group differently (rounding).  Slab loops, begin_local / phase callers and the Jacobi loop stay dense.
@@ -353,6 +353,14 @@ int mfs_vcg3d_set_compress(mfs_vcg3d* h, int on);
 /* census of those classes after mfs_vcg3d_setup: counts_host[0] = z-vectors whose samples are all 0, [1] = all 1,
  * [2] = the rest (the only ones that read the class arrays).  Diagnostic, host-synchronous. */
 int mfs_vcg3d_class_census(mfs_vcg3d* h, int64_t counts_host[3], mfs_stream stream);
+/* sparse lists of a single-domain solve (round 3; default on from 2^21 unknowns, env MFS_VISC_SPARSE / MFS_VISC_SPARSE_MIN): the
+ * r and d / x updates sweep the 32-unknown chunks holding a face whose row is not empty (or r, d != 0), and -- with the
+ * compressed class access -- the march launches of mfs_vcg3d_iterate visit only the (tile, plane) pairs that are not all air
+ * (their q = +0 was stored by the solve's initial q = A x; nothing else writes it).  Values as in the dense loop; the dot
+ * products group differently.  Slab loops, phase callers, the fused and the Jacobi loop stay dense.
+ * mfs_vcg3d_sparse_info (host-synchronous): out = {listed chunks, chunks, listed pairs, pairs} of the solve begun last. */
+int mfs_vcg3d_set_sparse(mfs_vcg3d* h, int on);
+int mfs_vcg3d_sparse_info(mfs_vcg3d* h, mfs_stream stream, int64_t out[4]);
 /* bit 0: mfs_vcg3d_iterate will run the fused 2-launch loop for the engine as bound and set up; bit 1: the small-problem
  * loop -- the r update (:592-601), the r.r reduction, the test / bookkeeping (:604-608) and the x / direction updates
  * (:595-597, :609-610) in ONE launch whose resident workgroups exchange their partial sums (csrc/mfs_cg_core.h

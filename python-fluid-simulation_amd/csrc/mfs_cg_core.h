@@ -76,29 +76,95 @@ __device__ __forceinline__ int64_t live_vec(const LiveMap& lm, int64_t k) {
   return lm.list ? (((int64_t)lm.list[k >> lm.shift] << lm.shift) | (k & ((1 << lm.shift) - 1))) : k;
 }
 
-constexpr int kLiveChunk = 1024;          // unknowns per chunk of a live map
+// unknowns per chunk of a live map: one 128-byte line of fp32 state (8 16-byte vectors).  Much smaller than a z-row of a
+// production grid on purpose -- a liquid body covers PART of a row: with 1024-unknown chunks (four whole rows at Nz = 256) the
+// vector phases of the 256^3 viscosity bench swept 18.7 % of the unknowns for 7 % of liquid, with 128 (half a row) 17.4 %
+constexpr int kLiveChunk = 32;
 
-// chunk flags -> list of live chunk indices + their count (ONE block; a few ten thousand chunks at most)
+// flags -> ascending list of the indices whose flag is set + their count, once per solve: per-block counts (coalesced
+// reads, ballots), a one-block scan of the block counts, then an ordered per-block compaction.  (A single block walking
+// the flags thread by thread -- the first version -- takes milliseconds at the 1.6 M chunks of a 256^3 viscosity solve.)
+constexpr int kCompactTile = 8192;        // flags per block: 1024 threads x 8
 template <typename F>
 static __global__ void __launch_bounds__(1024)
-k_live_list(const F* __restrict__ flags, int nchunks, int* __restrict__ list, int* __restrict__ count) {
-  const int t = threadIdx.x;
-  const int per = (nchunks + 1023) / 1024, i0 = min(nchunks, t * per), i1 = min(nchunks, i0 + per);
-  int sum = 0;
-  for (int i = i0; i < i1; ++i) sum += flags[i] != 0;
-  __shared__ int s_pre[1024];
-  s_pre[t] = sum;
+k_compact_count(const F* __restrict__ flags, int n, int* __restrict__ bsum) {
+  const int base = blockIdx.x * kCompactTile;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = base + j * 1024 + (int)threadIdx.x;
+    c += __popcll(__builtin_amdgcn_ballot_w64(i < n && flags[i] != 0));      // (every lane of a wave holds the wave's count)
+  }
+  __shared__ int s_w[16];
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = t >= o ? s_pre[t - o] : 0;
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += s_w[w];
+    bsum[blockIdx.x] = t;
+  }
+}
+
+// exclusive scan of the block counts in place, total -> *count (ONE block; nb is n / 8192)
+static __global__ void __launch_bounds__(1024)
+k_compact_scan(int* __restrict__ bsum, int nb, int* __restrict__ count) {
+  __shared__ int s_pre[1024];
+  __shared__ int s_carry;
+  const int t = threadIdx.x;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int v = b0 + t < nb ? bsum[b0 + t] : 0;
+    s_pre[t] = v;
     __syncthreads();
-    s_pre[t] += v;
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int u = t >= o ? s_pre[t - o] : 0;
+      __syncthreads();
+      s_pre[t] += u;
+      __syncthreads();
+    }
+    const int carry = s_carry;
+    if (b0 + t < nb) bsum[b0 + t] = carry + s_pre[t] - v;
+    __syncthreads();
+    if (t == 1023) s_carry = carry + s_pre[1023];
     __syncthreads();
   }
-  int run = s_pre[t] - sum;
-  for (int i = i0; i < i1; ++i)
-    if (flags[i] != 0) list[run++] = i;
-  if (t == 1023) *count = s_pre[1023];
+  if (t == 0) *count = s_carry;
+}
+
+template <typename F>
+static __global__ void __launch_bounds__(1024)
+k_compact_write(const F* __restrict__ flags, int n, const int* __restrict__ bsum, int* __restrict__ list) {
+  const int base = blockIdx.x * kCompactTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int s_w[2][16];
+  int run = bsum[blockIdx.x];
+#pragma unroll 1
+  for (int j = 0; j < 8; ++j) {
+    const int i = base + j * 1024 + (int)threadIdx.x;
+    const bool f = i < n && flags[i] != 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+    if (lane == 0) s_w[j & 1][wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = s_w[j & 1][w]; before += w < wave ? c : 0; total += c; }
+    if (f) list[run + before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    run += total;
+  }
+}
+
+// scratch: kCompactScratch(n) ints
+static inline size_t core_compact_scratch_ints(int64_t n) { return (size_t)((n + kCompactTile - 1) / kCompactTile) + 2; }
+template <typename F>
+static inline int core_compact_flags(const F* flags, int n, int* list, int* count, int* scratch, hipStream_t st) {
+  const int nb = (n + kCompactTile - 1) / kCompactTile;
+  if (nb <= 0) { MFS_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int), st)); return MFS_OK; }
+  hipLaunchKernelGGL(k_compact_count<F>, dim3(nb), dim3(1024), 0, st, flags, n, scratch);
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, scratch, nb, count);
+  hipLaunchKernelGGL(k_compact_write<F>, dim3(nb), dim3(1024), 0, st, flags, n, (const int*)scratch, list);
+  MFS_LAUNCH_CHECK();
+  return MFS_OK;
 }
 
 // work lists of the marching kernels: runrem[k] = how many consecutive list entries from k on are consecutive planes of one
@@ -114,7 +180,11 @@ k_list_runs(const int* __restrict__ items, const int* __restrict__ count, int np
   runrem[k] = r;
 }
 
-static inline size_t core_live_ws_bytes(int64_t n) { return align_up((size_t)(2 * ((n + kLiveChunk - 1) / kLiveChunk) + 64) * sizeof(int), 4096); }
+// flags | list | count (64 ints) | scratch of the compaction
+static inline size_t core_live_ws_bytes(int64_t n) {
+  const int64_t nch = (n + kLiveChunk - 1) / kLiveChunk;
+  return align_up((size_t)(2 * nch + 64 + core_compact_scratch_ints(nch)) * sizeof(int), 4096);
+}
 
 template <typename T, int VEC, typename F>
 __device__ __forceinline__ void for_each_vec(int64_t n, F&& f, bool reverse = false, bool blocked = false, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {

@@ -273,7 +273,9 @@ static int64_t skip_pairs(const int64_t gres[3], int dt) {
   const int64_t vec = dt == MFS_F32 ? 4 : 2;
   return ((gres[1] * (gres[2] / vec + 1) + kApplyBlock - 1) / kApplyBlock + 1) * (gres[0] + 1);
 }
-static size_t skip_ws_bytes(const int64_t gres[3], int dt) { return align_up((size_t)(3 * skip_pairs(gres, dt) + 64) * sizeof(int), 4096); }
+static size_t skip_ws_bytes(const int64_t gres[3], int dt) {
+  return align_up((size_t)(3 * skip_pairs(gres, dt) + 64 + core_compact_scratch_ints(skip_pairs(gres, dt))) * sizeof(int), 4096);
+}
 
 extern "C" {
 
@@ -585,11 +587,7 @@ k_pcg_live_flags(const unsigned char* __restrict__ cls, const T* __restrict__ r,
       if (x >= xb && x < xe && y >= 1 && y <= Ny - 2) tflags[(int64_t)(((y - 1) * nzv + zv) / kApplyBlock) * (xe - xb) + (x - xb)] = 1;
     }
   }
-  if (__builtin_amdgcn_ballot_w64(live) != 0 && (threadIdx.x & 63) == 0) {
-    const int64_t c0 = i0 / kLiveChunk, c1 = min(n - 1, i0 + 64 * VEC - 1) / kLiveChunk;
-    flags[c0] = 1;
-    if (c1 != c0) flags[c1] = 1;
-  }
+  if (live) flags[i0 / kLiveChunk] = 1;      // (a vector never straddles a chunk: both are multiples of VEC unknowns)
 }
 
 // slab: the window / collective slab loops -- the vector phases cover the owned planes [1, Nx-1), the fused interior launch
@@ -631,14 +629,13 @@ static int pcg_build_live(mfs_pcg3d* h, hipStream_t st, bool slab = false) {
   else
     hipLaunchKernelGGL((k_pcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls + off / vec, (const double*)h->c.r + off,
                        (const double*)h->c.d + off, cnt, flags, x_first, h->Ny, nzv, xb, xe, skip ? tflags : (int*)nullptr);
-  hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, flags, nchunks, list, count);
-  MFS_LAUNCH_CHECK();
+  if (int e = core_compact_flags<int>(flags, nchunks, list, count, count + 64, st)) return e;
   int shift = 0;
   while ((1 << shift) < kLiveChunk / vec) ++shift;
   h->c.live = LiveMap{list, count, shift};
   h->c.live_off = off; h->c.live_cnt = cnt;
   if (skip) {
-    hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, tflags, (int)npairs, items, scount);
+    if (int e = core_compact_flags<int>(tflags, (int)npairs, items, scount, scount + 64, st)) return e;
     hipLaunchKernelGGL(k_list_runs, dim3(cdiv(npairs, 256)), dim3(256), 0, st, items, scount, np, runrem);
     MFS_LAUNCH_CHECK();
     // the partner buffer of the direction vector must be 0 wherever the loop never writes it (a previous solve's liquid)

@@ -1079,7 +1079,7 @@ static int vcg_march_launch_nt(mfs_vcg3d* h, const Vec3T<T>& vv, T* ob, double* 
 
 // ---- live chunks of the flat CG vectors (mfs_cg_core.h LiveMap): a face is DEAD when its operator row is empty -- an
 // array-boundary face, a solid face, or all seven volume samples of its row 0 -- and r = d = 0 there at the start of the
-// loop (b - A x0 = 0): then q, r and d stay exactly 0 and x never changes.  A chunk of 1024 unknowns is live when any of
+// loop (b - A x0 = 0): then q, r and d stay exactly 0 and x never changes.  A chunk of 32 unknowns is live when any of
 // its faces is not dead.  Built once per solve (single-domain loops), behind the initial residual.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
@@ -1107,15 +1107,9 @@ k_vcg_live_flags(Compact c, const T* __restrict__ r, const T* __restrict__ d, in
       }
     }
   }
-  if (__builtin_amdgcn_ballot_w64(live) != 0 && (threadIdx.x & 63) == 0) {
-    // a wave's 64 vectors span at most two chunks
-    const int64_t c0 = i0 / kLiveChunk, c1 = min(n - 1, i0 + 64 * VEC - 1) / kLiveChunk;
-    flags[c0] = 1;
-    if (c1 != c0) flags[c1] = 1;
-  }
+  if (live) flags[i0 / kLiveChunk] = 1;      // (a vector never straddles a chunk: both are multiples of VEC unknowns)
 }
 
-// (a wave marks the chunks of ALL its 64 vectors live when any of them is: conservative, never wrong)
 static int vcg_build_live(mfs_vcg3d* h, hipStream_t st) {
   h->c.live = LiveMap{nullptr, nullptr, 0};
   if (!h->sparse_vec || !core_vec_ok(h->c) || h->n < h->sparse_min) return MFS_OK;
@@ -1130,7 +1124,7 @@ static int vcg_build_live(mfs_vcg3d* h, hipStream_t st) {
     hipLaunchKernelGGL((k_vcg_live_flags<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, (const float*)h->c.r, (const float*)h->c.d, h->n, h->off[1], h->off[2], flags);
   else
     hipLaunchKernelGGL((k_vcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cp, (const double*)h->c.r, (const double*)h->c.d, h->n, h->off[1], h->off[2], flags);
-  hipLaunchKernelGGL(k_live_list<int>, dim3(1), dim3(1024), 0, st, flags, nchunks, list, count);
+  if (int e = core_compact_flags<int>(flags, nchunks, list, count, count + 64, st)) return e;
   MFS_LAUNCH_CHECK();
   int shift = 0;
   while ((1 << shift) < kLiveChunk / vec) ++shift;
@@ -1184,8 +1178,8 @@ static int vcg_build_classes(mfs_vcg3d* h, hipStream_t stream) {
         }
         // the work list of the CG loop's launches: the busy pairs only (an all-air pair's q is +0 and stays what the
         // initial q = A x stored there)
-        if (nt < 0x7fffffff) {
-          hipLaunchKernelGGL(k_live_list<unsigned char>, dim3(1), dim3(1024), 0, stream, flags, (int)nt, h->list_items, h->list_count);
+        if (nt < 0x7fffffff && core_compact_scratch_ints(nt) + 16 <= 4096 / sizeof(int)) {      // (the scratch shares the count's page)
+          if (int e = core_compact_flags<unsigned char>(flags, (int)nt, h->list_items, h->list_count, h->list_count + 16, stream)) return e;
           hipLaunchKernelGGL(k_list_runs, dim3(cdiv(nt, 256)), dim3(256), 0, stream, h->list_items, h->list_count, Nx, h->list_runrem);
           MFS_LAUNCH_CHECK();
           h->list_ready = true;
@@ -1411,6 +1405,21 @@ static int vslab_allreduce(mfs_vcg3d* h, int slot, int check_done, int64_t episo
   return MFS_OK;
 }
 
+// Work list of the CG loops' march launches (Compact::items): attached for the duration of one loop call when the solve
+// has live-chunk vector phases (vcg_build_live: single-domain and window slab loops) -- q of an all-air (tile, plane) pair is
+// +0 since the solve's initial q = A x and nothing else writes it.  Stand-alone / phase-API applies never see the list.
+struct VcgListScope {
+  mfs_vcg3d* h;
+  int err = MFS_OK;
+  VcgListScope(mfs_vcg3d* h_, hipStream_t st) : h(h_) {
+    if (h->c.live.list && h->compress && !h->mask_cg) {
+      if (!h->classes_ready) err = vcg_build_classes(h, st);
+      if (!err && h->list_ready) { h->cp.items = h->list_items; h->cp.runrem = h->list_runrem; h->cp.count = h->list_count; }
+    }
+  }
+  ~VcgListScope() { h->cp.items = nullptr; h->cp.runrem = nullptr; h->cp.count = nullptr; }
+};
+
 template <typename T>
 static int vslab_iteration(mfs_vcg3d* h, hipStream_t st) {
   mfs_p2p* p = h->p2p;
@@ -1426,7 +1435,11 @@ static int vslab_iteration(mfs_vcg3d* h, hipStream_t st) {
                        grid);
     MFS_LAUNCH_CHECK();
   }
-  if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;
+  {
+    VcgListScope list(h, st);
+    if (list.err) return list.err;
+    if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;
+  }
   h->c.n_part_dq = np;
   if (h->jacobi) {
     // opt-in Jacobi iteration: three all-reduce episodes (d.q, r.r, r.z; begin used 0 and 1), the generic Jacobi kernels
@@ -1846,7 +1859,7 @@ int mfs_vcg3d_begin_local(mfs_vcg3d* h, double tol, mfs_stream stream) {
   MFS_REQUIRE(h && h->c.x && h->is_setup, "engine not bound / set up");
   hipStream_t st = (hipStream_t)stream;
   h->fused_run = false;
-  h->c.live = LiveMap{nullptr, nullptr, 0};      // slab loops sweep every chunk (ghost planes of d arrive from the neighbours)
+  h->c.live = LiveMap{nullptr, nullptr, 0};      // callers that drive the phases themselves sweep every chunk
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
@@ -1902,7 +1915,6 @@ int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   h->fused_run = false;
   h->c.live = LiveMap{nullptr, nullptr, 0};
-  h->c.live = LiveMap{nullptr, nullptr, 0};      // slab loops sweep every chunk (ghost planes of d arrive from the neighbours)
   if (int e = core_begin_pre(h->c, tol, false, st)) return e;
   int np = 0;
   if (int e = vcg_apply(h, h->c.x, h->c.q, h->c.part_dq, false, true, st, &np)) return e;
@@ -1925,7 +1937,10 @@ int mfs_vcg3d_slab_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
   }
   if (int e = core_begin_post(h->c, st, false)) return e;        // d = r = b - q, partials of r.r
   if (int e = vslab_allreduce(h, S_RR, 0, 0, st)) return e;
-  return core_begin_finish(h->c, st);
+  if (int e = core_begin_finish(h->c, st)) return e;
+  // (a face's liveness is a property of its own rank: an empty row gives q = 0 whatever the ghost planes hold; ghost faces are
+  // array-boundary faces of the local arrays -- never swept unless they share a chunk with a live face, as in the dense loop)
+  return h->fuse ? MFS_OK : vcg_build_live(h, st);
 }
 
 int mfs_vcg3d_slab_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
@@ -2098,11 +2113,8 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
   const bool rdx = core_rdx_ok(h->c) && !h->p2p;
   // single-domain solves with live-chunk vector phases (vcg_build_live): the march visits only the busy (tile, plane)
   // pairs -- q of an all-air pair is +0 since the initial q = A x and nothing else writes it
-  if (h->c.live.list && h->compress && !h->mask_cg) {
-    if (!h->classes_ready) { if (int e = vcg_build_classes(h, st)) return e; }
-    if (h->list_ready) { h->cp.items = h->list_items; h->cp.runrem = h->list_runrem; h->cp.count = h->list_count; }
-  }
-  struct ListOff { mfs_vcg3d* h; ~ListOff() { h->cp.items = nullptr; h->cp.runrem = nullptr; h->cp.count = nullptr; } } list_off{h};
+  VcgListScope list(h, st);
+  if (list.err) return list.err;
   for (int64_t i = 0; i < n; ++i) {
     int e, np = 0;
     if ((e = vcg_apply(h, h->c.d, h->c.q, h->c.part_dq, true, h->mask_cg != 0, st, &np))) return e;   // :589
@@ -2232,6 +2244,34 @@ int mfs_vcg3d_class_census(mfs_vcg3d* h, int64_t counts_host[3], mfs_stream stre
   MFS_HIP_TRY(hipStreamSynchronize(st));
   MFS_HIP_TRY(hipMemsetAsync(dv, 0, 3 * sizeof(unsigned long long), st));
   for (int k = 0; k < 3; ++k) counts_host[k] = (int64_t)host[k];
+  return MFS_OK;
+}
+
+int mfs_vcg3d_set_sparse(mfs_vcg3d* h, int on) {
+  MFS_REQUIRE(h, "null handle");
+  h->sparse_vec = on ? 1 : 0;
+  return MFS_OK;
+}
+
+// out = {live chunks, chunks, listed (tile, plane) pairs, pairs} of the solve begun last (zeros where a list is off); host-synchronous
+int mfs_vcg3d_sparse_info(mfs_vcg3d* h, mfs_stream stream, int64_t out[4]) {
+  MFS_REQUIRE(h && out, "null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (!h->c.live.count) return MFS_OK;
+  int v = 0;
+  MFS_HIP_TRY(hipMemcpyAsync(&v, h->c.live.count, sizeof(int), hipMemcpyDeviceToHost, st));
+  MFS_HIP_TRY(hipStreamSynchronize(st));
+  out[0] = v;
+  out[1] = (h->n + kLiveChunk - 1) / kLiveChunk;
+  if (h->compress && !h->mask_cg && h->classes_ready && h->list_ready) {
+    MFS_HIP_TRY(hipMemcpyAsync(&v, h->list_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    MFS_HIP_TRY(hipStreamSynchronize(st));
+    const int vec = h->dt == MFS_F32 ? 4 : 2;
+    const int ipp = (h->g.N[1] - 2) * (h->g.N[2] / vec);
+    out[2] = v;
+    out[3] = (int64_t)((ipp + h->cp.tw_block - 1) / h->cp.tw_block) * (h->g.N[0] - 2);
+  }
   return MFS_OK;
 }
 

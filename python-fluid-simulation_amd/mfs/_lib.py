@@ -139,6 +139,8 @@ SIGNATURES = {
     "mfs_vcg3d_set_compress": (_i, [_p, _i]),
     "mfs_vcg3d_set_resident": (_i, [_p, _i]),
     "mfs_vcg3d_class_census": (_i, [_p, _pi64, _p]),
+    "mfs_vcg3d_set_sparse": (_i, [_p, _i]),
+    "mfs_vcg3d_sparse_info": (_i, [_p, _p, _pi64]),
     "mfs_vcg3d_loop_info": (_i, [_p]),
     "mfs_vcg3d_set_merged": (_i, [_p, _i]),
     "mfs_vcg3d_set_jacobi": (_i, [_p, _i]),

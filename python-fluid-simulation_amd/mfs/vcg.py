@@ -99,6 +99,16 @@ class VcgEngine:
         _lib.check(self.lib.mfs_vcg3d_class_census(self.h, out, T.stream()), "mfs_vcg3d_class_census")
         return {"zero": int(out[0]), "one": int(out[1]), "mixed": int(out[2])}
 
+    def set_sparse(self, on):
+        """single-domain solves from 2^21 unknowns: live-chunk vector phases + work list of the loop's march launches"""
+        _lib.check(self.lib.mfs_vcg3d_set_sparse(self.h, int(bool(on))), "mfs_vcg3d_set_sparse")
+
+    def sparse_info(self):
+        import ctypes
+        out = (ctypes.c_int64 * 4)()
+        _lib.check(self.lib.mfs_vcg3d_sparse_info(self.h, T.stream(), out), "mfs_vcg3d_sparse_info")
+        return dict(live_chunks=int(out[0]), chunks=int(out[1]), listed_pairs=int(out[2]), pairs=int(out[3]))
+
     def set_fuse(self, on):
         _lib.check(self.lib.mfs_vcg3d_set_fuse(self.h, int(bool(on))), "mfs_vcg3d_set_fuse")
 

@@ -355,7 +355,7 @@ def _blob_problem(gres, centre, radius, seed):
 @pytest.mark.parametrize("dt", [torch.float64, torch.float32], ids=["f64", "f32"])
 def test_sparse_work_list_and_live_chunks_match_the_dense_loop(dt, monkeypatch):
     """round 3: behind the initial residual a single-domain solve lists the (tile, plane) pairs of the march that compute
-    anything and the 1024-cell chunks that hold a live unknown; the fused stencil launches and the r update visit only
+    anything and the 32-cell chunks that hold a live unknown; the fused stencil launches and the r update visit only
     those.  A ball of liquid in a 160 x 96 x 128 box (2 M cells: the size from which the lists are built) -- and then, THROUGH
     THE SAME ENGINE, a ball elsewhere (the partner buffer of the direction vector still holds the first solve's liquid) --
     against the engine with the lists off: same history to rounding (dot products group differently), same solution."""

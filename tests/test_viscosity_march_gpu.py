@@ -249,7 +249,7 @@ def test_compressed_class_access_on_hostile_volumes(dt):
 # ------------------------------------------------------------------ sparse lists of a single-domain solve (round 3) ----
 @pytest.mark.parametrize("prec", ["fp64", "fp32"])
 def test_sparse_lists_match_the_dense_loop(prec, monkeypatch):
-    """round 3, single-domain solves from 2^21 unknowns: the r and d / x updates sweep the live 1024-unknown chunks only and the
+    """round 3, single-domain solves from 2^21 unknowns: the r and d / x updates sweep the live 32-unknown chunks only and the
     loop's march launches visit only the busy (tile, plane) pairs (an all-air pair's q = +0 was stored by the solve's initial
     q = A x).  96^3 buckling-like scene (7 % liquid), then -- THROUGH THE SAME SOLVER, so that q, r, d hold the first
     solve's values where the liquid was -- the scene mirrored in x; against MFS_VISC_SPARSE=0: same iteration count (+-1),

@@ -38,8 +38,20 @@ def _assemble(g, res):
     ("v3d_a_12", 2, "f64", "rccl"), ("v3d_b_10x12x14", 3, "f64", "rccl"), ("v3d_a_12", 3, "f32", "rccl"),
 ])
 def test_slab_viscosity_matches_reference_outputs(name, world, dtname, transport, tmp_path):
+    _check_against_goldens(name, world, dtname, transport, tmp_path)
+
+
+@pytest.mark.parametrize("name,world,dtname", [("v3d_a_12", 1, "f64"), ("v3d_b_10x12x14", 2, "f64"), ("v3d_b_10x12x14", 3, "f64"),
+                                               ("v3d_a_12", 3, "f32"), ("v3d_c_16_mu50", 2, "f64")])
+def test_slab_viscosity_sparse_lists(name, world, dtname, tmp_path):
+    """round 3: the window slab loop with the solve's sparse lists (live chunks for the vector phases, busy (tile, plane) pairs
+    for the march launches), forced onto these small grids with MFS_VISC_SPARSE_MIN=1: the same checks against the goldens"""
+    _check_against_goldens(name, world, dtname, "p2p", tmp_path, MFS_VISC_SPARSE_MIN="1", MFS_VISC_RESIDENT="0", MFS_RDX="0")
+
+
+def _check_against_goldens(name, world, dtname, transport, tmp_path, **env):
     g = golden(name)
-    res = _run_ranks(name, world, tmp_path, dtname, P2P_TEST_MODE="viscosity", P2P_TEST_TRANSPORT=transport)
+    res = _run_ranks(name, world, tmp_path, dtname, P2P_TEST_MODE="viscosity", P2P_TEST_TRANSPORT=transport, **env)
     assert all(str(r["transport"]) == transport for r in res)
     a = _assemble(g, res)
     for r in res:          # ghost planes of q and r stay exactly 0: the local dot products count owned faces only
