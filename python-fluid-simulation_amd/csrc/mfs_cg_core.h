@@ -1167,6 +1167,7 @@ static inline int core_bind(CgCore& c, void* b, void* x, void* d, void* r, void*
     for (int j = i + 1; j < 5; ++j) MFS_REQUIRE(a[i] != a[j], "CG vectors must be distinct arrays");
   }
   c.b = b; c.x = x; c.d = d; c.r = r; c.q = q;
+  c.live = LiveMap{nullptr, nullptr, 0};      // a solve's lists describe the vectors it began with
   return MFS_OK;
 }
 

@@ -402,6 +402,8 @@ static int pcg_setup_impl(mfs_pcg3d* h, const void* lphi, int lphi_dt, const voi
     MFS_LAUNCH_CHECK();
   }
   h->is_setup = true;
+  h->c.live = LiveMap{nullptr, nullptr, 0};      // a solve's sparse lists belong to the operator it began with
+  h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
   return MFS_OK;
 }
 
@@ -427,6 +429,7 @@ int mfs_pcg3d_apply(mfs_pcg3d* h, const void* v, void* out, int64_t x_begin, int
 
 int mfs_pcg3d_bind(mfs_pcg3d* h, void* b, void* x, void* d, void* r, void* q) {
   MFS_REQUIRE(h, "null handle");
+  h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
   return core_bind(h->c, b, x, d, r, q);
 }
 
@@ -1048,8 +1051,9 @@ int mfs_pcg3d_solve(mfs_pcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   bool first = true;
   while (!done && enq < max_iter) {
     // the resident loop stops by itself inside a batch (one launch), so a longer batch costs nothing but saves the
-    // launch, the reload of the state and the poll: at least 128 iterations per look there
-    const int64_t every = resident_ok(h) ? std::max<int64_t>(check_every, 128) : check_every;
+    // launch, the reload of the state and the look (a stream synchronisation: ~25 us, three or four iterations' worth): at
+    // least 1024 iterations per look there -- the notebook's solves (300 .. 600 iterations) then cost one look each
+    const int64_t every = resident_ok(h) ? std::max<int64_t>(check_every, 1024) : check_every;
     int64_t n = std::min(every, max_iter - enq);
     // launch-per-phase loops, SHORT solves (up to 4 x check_every iterations, where a look at the scalar block costs as much as
     // half a dozen iterations): the first batch is sized by this engine's previous solve -- consecutive time steps need about

@@ -1783,6 +1783,8 @@ int mfs_vcg3d_setup(mfs_vcg3d* h, double scale, double mu, const void* sphi, int
                        (double*)v[5], (double*)v[6], (double*)v[7], mp);
   MFS_LAUNCH_CHECK();
   h->classes_ready = false;    // the march's compressed class access builds its classes at its first launch (vcg_build_classes)
+  h->list_ready = false;
+  h->c.live = LiveMap{nullptr, nullptr, 0};      // a solve's sparse lists belong to the operator it began with
   h->k1 = scale * mu;          // `scale * mu * ...`      (left to right, as the reference evaluates it)
   h->k2 = 2 * scale * mu;      // `2 * scale * mu * ...`
   h->is_setup = true;
@@ -2190,8 +2192,10 @@ int mfs_vcg3d_solve(mfs_vcg3d* h, double tol, int64_t max_iter, int64_t check_ev
   // where an overshooting prediction costs more no-op launches than the looks it saves --: `check_every` as before.
   bool first = true;
   while (!done && enq < max_iter) {
-    int64_t n = std::min(check_every, max_iter - enq);
-    if (first && h->last_iters > 0 && h->last_iters <= 4 * check_every)
+    // (the resident loop stops by itself inside a batch -- one launch --: at least 1024 iterations per look there)
+    const bool res = vcg_resident_ok(h);
+    int64_t n = std::min(res ? std::max<int64_t>(check_every, 1024) : check_every, max_iter - enq);
+    if (!res && first && h->last_iters > 0 && h->last_iters <= 4 * check_every)
       n = std::min<int64_t>(max_iter - enq, std::min<int64_t>(h->last_iters + h->last_iters / 8 + 2, h->last_iters + 256));
     first = false;
     if (int e = mfs_vcg3d_iterate(h, n, stream)) return e;
