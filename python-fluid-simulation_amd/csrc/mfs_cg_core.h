@@ -42,6 +42,7 @@ enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TO
        S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
        S_LASTRR = MFS_PCG_S_LASTRR, S_RING = 9 /* 2 slots: delta by iteration parity */,
        S_RZ = 12 /* Jacobi loop: r.z of the latest update */,
+       S_LANE = 13 /* pressure engine: 1 when lane-level masking of the listed launches pays on this solve (pcg_build_live) */,
        S_ERR = MFS_PCG_S_ERR /* != 0: the solve was stopped -- 1 / 2 a peer-to-peer wait timed out (slab loop: all-reduce /
                                 halo plane), 3 d.q == 0 (the reference's ZeroDivisionError, PressureCGSolver3D.py:211),
                                 4 a non-finite d.q or r.r (the reference would spin to max_iter on `nan < tol**2`) */ };
@@ -949,7 +950,10 @@ k_jac_update_d(T* __restrict__ d, const T* __restrict__ r, const T* __restrict__
 }
 
 // class byte per 16-byte z-vector of the pressure engine's coefficient arrays (mfs_pcg_apply.h: compressed coefficient access)
-enum : unsigned char { kClsZero = 0, kClsRegular = 1, kClsMixed = 2 };
+// kClsDead (round 3): a ZERO vector whose r and d were 0 when the solve's sparse lists were built -- q, r, d stay +0 and x
+// untouched there for the whole solve.  Written over kClsZero by k_pcg_live_flags, honoured ONLY by launches that carry
+// the solve's work list (every other consumer treats it as kClsZero: it compares against REGULAR / MIXED).
+enum : unsigned char { kClsZero = 0, kClsRegular = 1, kClsMixed = 2, kClsDead = 3 };
 
 // ---- the FUSED Jacobi loop (2 launches + a one-block bookkeeping launch per iteration): z = r / diag is STORED by the
 // r update -- which reads diag anyway for r.z -- into an engine buffer, and the stencil launch of the next iteration forms

@@ -117,6 +117,7 @@ struct mfs_pcg3d {
   hipEvent_t ev_main, ev_aux;
   const int *skip_items, *skip_runrem, *skip_count;   // sparse work list of the fused stencil launches (null: dense), per solve
   int skip_xb, skip_xe;        // ... built for the launch over the planes [skip_xb, skip_xe)
+  bool lane_mask;              // ... and whether its launches mask dead lanes (from the scalar block of the latest poll)
   int* skip_ws;                // tile flags | items | runrem | count
   int sparse_vec;              // 1 (default; MFS_SPARSE): the r update of a single-domain solve sweeps live chunks only (LiveMap)
   int64_t sparse_min;          // ... from this many cells on
@@ -151,6 +152,7 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
   if (fz && h->skip_items && h->compress != 0 && VEC > 1 && xb == h->skip_xb && xe == h->skip_xe && xe2 == xb2 && variant >= 2) {
     a.items = h->skip_items; a.runrem = h->skip_runrem; a.count = h->skip_count;
   }
+  const bool lmask = a.items != nullptr && h->lane_mask && VEC > 1;
   const int np = (xe - xb) + (xe2 - xb2);
   if (variant == 0) {
     const int64_t items = (int64_t)np * ipp;
@@ -187,11 +189,14 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
     } else if (fz && fz->book) {
       // fused direction update + the bookkeeping of the previous iteration (PD 1), with or without the deferred x update
       const BookArgs bk{h->c.scal, h->c.hist, kHistCap, h->c.part_rr, h->c.n_part_rr, (int)((h->c.iter_enq - 1) & 1)};
-#define MFS_GO_B(NTV, CMP, ASY, XDF)                                                                                   \
-      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, XDF, true>), dim3(grid),             \
+#define MFS_GO_BM(NTV, CMP, ASY, XDF, LMK)                                                                            \
+      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, XDF, true, LMK>), dim3(grid),        \
                          dim3(kApplyBlock), lds, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done,                 \
                          (const T*)fz->r, (const T*)fz->d_old, (T*)fz->d_new, (const double*)nullptr, cz2,             \
                          (T*)fz->xdef, (const double*)nullptr, bk)
+      // (LMASK only with compressed access, and only when the launch carries the work list)
+#define MFS_GO_B(NTV, CMP, ASY, XDF)                                                                                   \
+      do { if (CMP && lmask) MFS_GO_BM(NTV, CMP, ASY, XDF, CMP); else MFS_GO_BM(NTV, CMP, ASY, XDF, false); } while (0)
       if (fz->xdef && asym) {      // (the density operator's -z tap and the deferred x update are independent of each other)
         if (comp) { if (nt) MFS_GO_B(7, true, true, true); else MFS_GO_B(0, true, true, true); }
         else      { if (nt) MFS_GO_B(7, false, true, true); else MFS_GO_B(0, false, true, true); }
@@ -206,13 +211,16 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
         else      { if (nt) MFS_GO_B(7, false, false, false); else MFS_GO_B(0, false, false, false); }
       }
 #undef MFS_GO_B
+#undef MFS_GO_BM
     } else if (fz && fz->xdef) {
       // fused direction update + the previous iteration's x update (PD 1 only); symmetric or density operator
-#define MFS_GO_X(NTV, CMP, ASY)                                                                                        \
-      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, true>), dim3(grid), dim3(kApplyBlock), \
+#define MFS_GO_XM(NTV, CMP, ASY, LMK)                                                                                  \
+      hipLaunchKernelGGL((k_pcg_apply_march<T, VEC, true, NTV, CMP, true, 1, ASY, true, false, LMK>), dim3(grid), dim3(kApplyBlock), \
                          lds, st, v, out, dg, cx, cy, cz, h->cls, a, partial, done, (const T*)fz->r, (const T*)fz->d_old, \
                          (T*)fz->d_new, (const double*)(h->c.scal + S_BETA), cz2, (T*)fz->xdef,                          \
                          (const double*)(h->c.scal + S_ALPHA))
+#define MFS_GO_X(NTV, CMP, ASY)                                                                                        \
+      do { if (CMP && lmask) MFS_GO_XM(NTV, CMP, ASY, CMP); else MFS_GO_XM(NTV, CMP, ASY, false); } while (0)
       if (asym) {
         if (comp) { if (nt) MFS_GO_X(7, true, true); else MFS_GO_X(0, true, true); }
         else      { if (nt) MFS_GO_X(7, false, true); else MFS_GO_X(0, false, true); }
@@ -221,6 +229,7 @@ static int launch_apply_v(mfs_pcg3d* h, const T* v, T* out, int xb, int xe, int 
         else      { if (nt) MFS_GO_X(7, false, false); else MFS_GO_X(0, false, false); }
       }
 #undef MFS_GO_X
+#undef MFS_GO_XM
     } else if (asym) {
       if (fz) MFS_GO_NT_CMP(true, 1, true); else MFS_GO_NT_CMP(false, 1, true);
     } else if (fz) {
@@ -328,6 +337,7 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->live_ws = (int*)((char*)h->part_rz + align_up((size_t)kMaxPartials * 8, 4096) + res_ws_bytes(h->n, h->c.elt));
   h->skip_ws = (int*)((char*)h->live_ws + core_live_ws_bytes(h->n));
   h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
+  h->lane_mask = false;
   h->sparse_vec = env_int("MFS_SPARSE", 1);
   h->sparse_min = (int64_t)env_int("MFS_SPARSE_MIN", 1 << 21);
   h->jacobi = env_int("MFS_JACOBI", 0);
@@ -575,22 +585,37 @@ static bool native_fuse_ok(const mfs_pcg3d* h);
 // a pure streaming kernel, sweeps the live chunks only.  Single-domain loops; built behind the initial residual.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-k_pcg_live_flags(const unsigned char* __restrict__ cls, const T* __restrict__ r, const T* __restrict__ d, int64_t n, int* __restrict__ flags,
-                 int x_first, int Ny, int nzv, int xb, int xe, int* __restrict__ tflags) {
+k_pcg_live_flags(unsigned char* __restrict__ cls, const T* __restrict__ r, const T* __restrict__ d, int64_t n, int* __restrict__ flags,
+                 int x_first, int Ny, int nzv, int xb, int xe, int* __restrict__ tflags, int* __restrict__ nlive) {
   // cls, r, d start at plane x_first of the arrays; n elements from there; the march's planes are [xb, xe)
   const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i0 = iv * VEC;
-  bool live = false;
+  bool live = false, counted = false;
   if (i0 < n) {
-    live = cls[iv] != kClsZero;
+    const unsigned char c = cls[iv];
+    const bool zero_row = c == kClsZero || c == kClsDead;      // (a mark of the engine's previous solve is re-decided here)
+    live = !zero_row;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) live = live || r[i0 + j] != (T)0 || d[i0 + j] != (T)0;
+    if (zero_row) cls[iv] = live ? kClsZero : kClsDead;        // lane-level: the listed launches move nothing for a dead vector
     if (live && tflags) {      // ... and the march's (tile, plane) pair of this vector (interior vectors only: the others are never computed)
       const int zv = (int)(iv % nzv), y = (int)((iv / nzv) % Ny), x = x_first + (int)(iv / ((int64_t)nzv * Ny));
-      if (x >= xb && x < xe && y >= 1 && y <= Ny - 2) tflags[(int64_t)(((y - 1) * nzv + zv) / kApplyBlock) * (xe - xb) + (x - xb)] = 1;
+      if (x >= xb && x < xe && y >= 1 && y <= Ny - 2) {
+        tflags[(int64_t)(((y - 1) * nzv + zv) / kApplyBlock) * (xe - xb) + (x - xb)] = 1;
+        counted = true;
+      }
     }
   }
+  if (nlive) {      // live vectors inside the march's pairs (one atomic per wave): what fraction of the listed pairs' lanes is dead?
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(counted);
+    if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(nlive, __popcll(m));
+  }
   if (live) flags[i0 / kLiveChunk] = 1;      // (a vector never straddles a chunk: both are multiples of VEC unknowns)
+}
+
+// lane-level masking of the listed launches (mfs_pcg_apply.h MASK) on when more than a quarter of the listed pairs' vectors are dead
+static __global__ void k_pcg_lane_mask_flag(const int* __restrict__ sc, double* __restrict__ scal) {
+  if (threadIdx.x == 0) scal[S_LANE] = ((long long)sc[1] * 4 < (long long)sc[0] * kApplyBlock * 3) ? 1.0 : 0.0;
 }
 
 // slab: the window / collective slab loops -- the vector phases cover the owned planes [1, Nx-1), the fused interior launch
@@ -625,13 +650,14 @@ static int pcg_build_live(mfs_pcg3d* h, hipStream_t st, bool slab = false) {
   int* runrem = items + npairs;
   int* scount = runrem + npairs;
   if (skip) MFS_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)npairs * sizeof(int), st));
+  if (skip) MFS_HIP_TRY(hipMemsetAsync(scount, 0, 64 * sizeof(int), st));      // [0] listed pairs, [1] live vectors in them
   const int64_t nvec = cnt / vec;
   if (h->dt == MFS_F32)
     hipLaunchKernelGGL((k_pcg_live_flags<float, 4>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls + off / vec, (const float*)h->c.r + off,
-                       (const float*)h->c.d + off, cnt, flags, x_first, h->Ny, nzv, xb, xe, skip ? tflags : (int*)nullptr);
+                       (const float*)h->c.d + off, cnt, flags, x_first, h->Ny, nzv, xb, xe, skip ? tflags : (int*)nullptr, skip ? scount + 1 : (int*)nullptr);
   else
     hipLaunchKernelGGL((k_pcg_live_flags<double, 2>), dim3(cdiv(nvec, 256)), dim3(256), 0, st, h->cls + off / vec, (const double*)h->c.r + off,
-                       (const double*)h->c.d + off, cnt, flags, x_first, h->Ny, nzv, xb, xe, skip ? tflags : (int*)nullptr);
+                       (const double*)h->c.d + off, cnt, flags, x_first, h->Ny, nzv, xb, xe, skip ? tflags : (int*)nullptr, skip ? scount + 1 : (int*)nullptr);
   if (int e = core_compact_flags<int>(flags, nchunks, list, count, count + 64, st)) return e;
   int shift = 0;
   while ((1 << shift) < kLiveChunk / vec) ++shift;
@@ -640,6 +666,7 @@ static int pcg_build_live(mfs_pcg3d* h, hipStream_t st, bool slab = false) {
   if (skip) {
     if (int e = core_compact_flags<int>(tflags, (int)npairs, items, scount, scount + 64, st)) return e;
     hipLaunchKernelGGL(k_list_runs, dim3(cdiv(npairs, 256)), dim3(256), 0, st, items, scount, np, runrem);
+    hipLaunchKernelGGL(k_pcg_lane_mask_flag, dim3(1), dim3(64), 0, st, (const int*)scount, h->c.scal);
     MFS_LAUNCH_CHECK();
     // the partner buffer of the direction vector must be 0 wherever the loop never writes it (a previous solve's liquid)
     MFS_HIP_TRY(hipMemsetAsync(h->d2, 0, (size_t)h->n * h->c.elt, st));
@@ -989,6 +1016,9 @@ int mfs_pcg3d_poll(mfs_pcg3d* h, mfs_stream stream, int64_t* iters, int* done, d
     h->c.iter_enq = (int64_t)h->c.pinned[S_ITERS];
     fresh = false;
   }
+  // lane-level masking of the listed launches (mfs_pcg_apply.h LMASK): this solve's decision arrives with the scalar block;
+  // launches enqueued from here on -- and the next solve's first batch -- take it (the class marks are per solve either way)
+  h->lane_mask = h->c.pinned[S_LANE] != 0.0;
   return core_poll(h->c, st, iters, done, delta, alpha, beta, fresh);
 }
 

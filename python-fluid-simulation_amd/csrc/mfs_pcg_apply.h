@@ -300,7 +300,7 @@ struct BookArgs {
 };
 
 template <typename T, int VEC, bool LDS, int NT, bool COMP, bool FUSE, int PD, bool ASYM = false, bool XDEF = false,
-          bool BOOK = false>
+          bool BOOK = false, bool LMASK = false>
 __global__ void __launch_bounds__(kApplyBlock, MFS_MARCH_MIN_WAVES)
 k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restrict__ diag,
                   const T* __restrict__ cx, const T* __restrict__ cy, const T* __restrict__ cz,
@@ -309,6 +309,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
                   T* __restrict__ fd_new, const double* __restrict__ beta_ptr, const T* __restrict__ cz2,
                   T* __restrict__ xdef = nullptr, const double* __restrict__ alpha_ptr = nullptr, BookArgs bk = BookArgs{}) {
   static_assert(!XDEF || FUSE, "the deferred x update rides on the fused direction update");
+  static_assert(!LMASK || (COMP && FUSE && PD == 1), "lane-level masking: compressed, fused, prefetch depth 1");
   static_assert(!BOOK || FUSE, "closing the previous iteration rides on the fused direction update");
   static_assert(kApplyBlock == kBlock, "block_total_of is written for kBlock threads");
   double alpha_x = (XDEF && !BOOK) ? *alpha_ptr : 0.0;
@@ -341,6 +342,7 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
   // `xchunk` > 0 additionally caps the length of one march.
   const bool sparse = a.items != nullptr;
   const int64_t total = sparse ? (int64_t)*a.count : (int64_t)tiles * np;
+
   const int G = gridDim.x;
   const int nch = min(G, kXcds);
   const int xcd = blockIdx.x % nch, slot = blockIdx.x / nch;
@@ -396,10 +398,21 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
     int64_t base = (int64_t)x0 * sx + m;
     const RawVec<T, VEC> wm = src.raw(base - sx), wc = src.raw(base), wp = src.raw(base + sx);
     // classes of this vector in planes x0 and x0+1 (compressed mode), then plane x0's coefficients
-    unsigned char cls_n = kClsMixed, cls_c = kClsMixed;
+    // MASK (template flag LMASK; sparse launches of the fused PD-1 forms when the solve's dead fraction makes it pay -- it costs
+    // ~1 % where every lane of a listed pair is live, the pool scene of the bench, and saves 10 % of the launch where half
+    // of them are dead, the 256^3 time step): a DEAD vector (kClsDead: ZERO row, r = d = 0 when the solve's lists
+    // were built) moves nothing in the steady state -- its r, d_old, x loads and its q, d_new, x stores are exec-masked
+    // (zeros stand for the operands: exactly what the loads would return; q and the partner d buffer hold +0 there since
+    // the solve began).  A liquid body covers PART of a tile's rows: in the 256^3 time step half the lanes of a listed
+    // pair are air.  The class of plane x+2 must be known when its operand load is issued: classes run three planes ahead.
+    // The prologue's own three planes and the halo rows are fetched unmasked.
+    constexpr bool MASK = LMASK;       // (a template flag, chosen per launch on the host: as a run-time flag it cost the pool scene 2 %)
+    const bool mask_on = MASK && sparse;
+    unsigned char cls_n = kClsMixed, cls_c = kClsMixed, cls_n2 = kClsMixed;
     if (COMP) {
       cls_c = cls[base / VEC];
       cls_n = cls[(base + (x0 + 1 < x1 ? sx : 0)) / VEC];
+      if (MASK) cls_n2 = cls[((int64_t)min(x0 + 2, x1) * sx + m) / VEC];
     }
     // this lane's first halo vector of plane x0 (requested with the rest of the batch, consumed when the image is staged)
     RawVec<T, VEC> wh = {};
@@ -453,14 +466,16 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       // waits for them where they are consumed (the rotation below), not here.
       const int64_t nn = more ? nb : base;                  // plane x+1 (or x again on the last step)
       const int64_t n2 = more ? nb + sx : nb;               // plane x+2 (or x+1 again)
-      const RawVec<T, VEC> qn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + m);   // operand vector, plane x+1+PD
+      const bool dead_c = mask_on && cc.cls == kClsDead;    // this step's own vector
+      RawVec<T, VEC> qn = {};                               // operand vector, plane x+1+PD (MASK: not for a dead vector)
+      if (!(mask_on && cls_n2 == kClsDead)) qn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + m);
       vec_t<T, VEC> xo = {}, dxo = {};                      // XDEF: this step's own x vector and d_old (cache hit)
-      if (XDEF) { xo = vload_nt<T, VEC>(xdef + base); dxo = vload<T, VEC>(fd_old + base); }
+      if (XDEF && !dead_c) { xo = vload_nt<T, VEC>(xdef + base); dxo = vload<T, VEC>(fd_old + base); }
       // plane x+1's coefficients (class known since the previous step); class of plane x+2
       CoefVec<T, VEC> cn = coef_load<T, VEC, COMP, NT, false, ASYM>(diag, cx, cy, cz, nn, sx, Nz, more ? cls_n : cc.cls, cz2);
       cn.cxm = cc.cxp;                                      // cx[x+1] was this step's upper-face weight
-      unsigned char cls_nn = kClsMixed;
-      if (COMP) cls_nn = cls[n2 / VEC];
+      unsigned char cls_nn = kClsMixed;                     // plain: class of plane x+2; MASK: of plane x+3 (x+2's is cls_n2)
+      if (COMP) cls_nn = MASK ? cls[((int64_t)min(x + 3, x1) * sx + m) / VEC] : cls[n2 / VEC];
       RawVec<T, VEC> hn = {};                               // this thread's halo vector of plane x+1+PD
       if (hact) hn = src.raw((int64_t)min(x + 1 + PD, x1) * sx + hg);
       // ---- in-plane neighbours of plane x
@@ -482,9 +497,9 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
       const T czs = __shfl_down(cc.czm[0], 1, 64);
       const double czr = (double)((lane == 63 && !last) ? cz[base + VEC] : czs);
       stencil_vec<T, VEC>(out + base, vc, vp, vm, vyp, vym, cc.dg, cc.cxp, cc.cxm, cc.cyp, cc.cym, cc.czm, zl, zr, czr,
-                          first, last, active, acc, cc.czm2);
-      if (FUSE && active) vstore<T, VEC>(fd_new + base, vc);   // d_new of this vector (its z-boundary cells are 0 + beta*0)
-      if (XDEF && active) {
+                          first, last, active && !dead_c, acc, cc.czm2);
+      if (FUSE && active && !dead_c) vstore<T, VEC>(fd_new + base, vc);   // d_new of this vector (its z-boundary cells are 0 + beta*0)
+      if (XDEF && active && !dead_c) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) xo[j] = (T)((double)xo[j] + alpha_x * (double)dxo[j]);
         vstore_nt<T, VEC>(xdef + base, xo);
@@ -503,7 +518,8 @@ k_pcg_apply_march(const T* __restrict__ v, T* __restrict__ out, const T* __restr
           }
           MFS_LDS_BARRIER();
         }
-        vm = vc; vc = vp; vp = src.fin(PD == 1 ? qn : Q[0]); cc = cn; cls_n = cls_nn;
+        vm = vc; vc = vp; vp = src.fin(PD == 1 ? qn : Q[0]); cc = cn;
+        if (MASK) { cls_n = cls_n2; cls_n2 = cls_nn; } else cls_n = cls_nn;
 #pragma unroll
         for (int k = 0; k + 1 < PD - 1; ++k) Q[k] = Q[k + 1];
         if (PD > 1) Q[PD - 2] = qn;

@@ -24,6 +24,7 @@ ABI_VERSION = 3
 # scalar slots of the CG engine's device block (include/mfs.h)
 S_DQ, S_RR, S_DELTA, S_TOL2, S_DONE, S_ITERS, S_ALPHA, S_BETA, S_LASTRR = range(9)
 S_ERR = 11         # != 0: the device loop stopped itself (include/mfs.h: MFS_PCG_S_ERR)
+S_LANE = 13        # pressure engine, diagnostics: 1 when the solve's listed launches mask dead lanes (csrc/mfs_pcg_apply.h LMASK)
 NSCALARS = 16
 
 

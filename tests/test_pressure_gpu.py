@@ -31,7 +31,7 @@ import pytest
 import torch
 
 from conftest import golden, golden_names
-from mfs import scenes
+from mfs import _lib, scenes
 from oracle import mfs_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -376,6 +376,9 @@ def test_sparse_work_list_and_live_chunks_match_the_dense_loop(dt, monkeypatch):
             ok, it = eng.solve(1e-6 if dt == torch.float64 else 1e-3, 4000, 16)
             torch.cuda.synchronize()
             assert ok
+            # a ball in a box: most lanes of the listed (tile, plane) pairs are dead, so the solve switches its listed launches to
+            # the lane-masking form at its first look at the scalar block (and the engine's next solve starts with it)
+            assert float(eng.scalars[_lib.S_LANE]) == (1.0 if sparse == "1" else 0.0)
             res.append((it, np.asarray(eng.history()), x.clone(), q.clone()))
         outs[sparse] = res
     for (it_s, h_s, x_s, q_s), (it_d, h_d, x_d, q_d) in zip(outs["1"], outs["0"]):
