@@ -661,6 +661,9 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       // the operands' signs) or NaN for a non-finite operand; the skip stores +0: equal in value (==), not in the sign
       // bit of a zero.  Planes are still fetched and published (neighbouring waves tap them), q is still stored.
       const bool skip = COMP && (!reads || __builtin_amdgcn_ballot_w64(((msk >> 4) & 3u) != kVmClsZero) == 0);
+      // work-list launches: q of an all-air VECTOR is +0 since the solve's initial q = A x, like that of an all-air pair --
+      // its three stores are not issued (lane level: a liquid body covers part of a tile's rows)
+      const bool qst = active && !(listed && ((msk >> 4) & 3u) == kVmClsZero);
       V qu = V{};
       if (!skip) {
       rg.um = vload<T, VEC>(bm + lu); rg.uc = vload<T, VEC>(bc + lu); rg.up = vload<T, VEC>(bn + lu);
@@ -677,7 +680,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       MFS_VM_ROWS_END();
       }
       MFS_VM_STAMP(4);                                           // u: rows (includes the wait for this step's class samples)
-      if (active) vm_store<T, VEC, true, NT>(ox + (int64_t)x * su + o_uv, qu, first, last);
+      if (COMP ? qst : active) vm_store<T, VEC, true, NT>(ox + (int64_t)x * su + o_uv, qu, first, last);
       MFS_VM_PIN();
       // COMP: the next step's class (its mask word has been in flight for a whole step) and the constant that stands
       // for every sample of a ZERO / ONE vector; only MIXED vectors (ldn) issue class loads -- exec-masked, lane by lane
@@ -715,7 +718,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       MFS_VM_ROWS_END();
       }
       MFS_VM_STAMP(7);                                           // v: rows
-      if (active) vm_store<T, VEC, true, NT>(oy + (int64_t)x * sv + o_uv, qv, first, last);
+      if (COMP ? qst : active) vm_store<T, VEC, true, NT>(oy + (int64_t)x * sv + o_uv, qv, first, last);
       MFS_VM_PIN();
       V fyn = kv, cymn = kv, exypn = kv;
       T eyzzrn = (T)0;
@@ -750,7 +753,7 @@ k_vcg_apply_march(Compact c, double k1, double k2, Vec3T<T> v, T* __restrict__ o
       MFS_VM_ROWS_END();
       }
       MFS_VM_STAMP(10);                                          // w: rows
-      if (active) vm_store<T, VEC, false, NT>(oz + (int64_t)x * sw + o_w, qw, first, last);
+      if (COMP ? qst : active) vm_store<T, VEC, false, NT>(oz + (int64_t)x * sw + o_w, qw, first, last);
       MFS_VM_PIN();
       V fzn = kv, exzpn = kv, eyzcn = kv, eyzypn = kv;
       T czln = (T)0;

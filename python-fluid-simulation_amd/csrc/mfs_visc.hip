@@ -306,7 +306,8 @@ k_vcg_bulk_value(Compact c, T* out) {
 }
 
 // Compressed class access of the x-marching kernel (mfs_vcg_march.h, COMP): the class of every interior z-vector -- are
-// ALL class samples its step loads +0.0 (bit 4), all exactly the set-up's bulk value (bit 5), or anything else (neither)? -- into bits 4-5
+// ALL class samples its step loads (and the three its rows take from the neighbouring vectors) +0.0 (bit 4), all its own exactly the
+// set-up's bulk value (bit 5), or anything else (neither)? -- into bits 4-5
 // of the mask byte of the vector's first cell (every reader of the mask bytes extracts single bits 0-2).  Bit patterns
 // are compared (a -0.0 is "anything else"), so the constant that stands for a load IS what the load returns.  Runs behind
 // k_vcg_setup in the same stream, once per set-up.
@@ -336,6 +337,14 @@ k_vcg_classify(Compact c, unsigned char* mp) {
   chk(1, sc); chk(1, c.pz);            // EXY at x+1, y+1
   chk(2, sc);                          // EXZ at x+1
   chk(4, c.pz);                        // EYZ at y+1
+  // ZERO also promises that every ROW of the vector's cells is empty (the march skips all-ZERO waves and tiles, and its work-list
+  // launches do not store q for a ZERO vector): the three class operands the rows take from the NEIGHBOURING vectors' registers
+  // -- C at z0-1, EXZ and EYZ at z0+VEC -- must be +0 as well.  (A liquid surface lying exactly on a vector boundary has
+  // all of this vector's own samples 0 and EXZ[z0+VEC] > 0: the last cell's u row is then not empty.)
+  if (zero) {
+    if (zv > 0) zero = vcg_is_pos_zero<T>(((const T*)c.vol[7])[base - 1]);
+    if (zero && zv < nzv - 1) zero = vcg_is_pos_zero<T>(((const T*)c.vol[2])[base + VEC]) && vcg_is_pos_zero<T>(((const T*)c.vol[4])[base + VEC]);
+  }
   mp[base] = (unsigned char)((mp[base] & 0x0f) | (zero ? 0x10 : (one ? 0x20 : 0)));
 }
 

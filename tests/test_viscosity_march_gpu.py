@@ -149,6 +149,14 @@ def _torch_census(gres, vol, vec):
     parts = [win(p, 0, 0) for p in range(1, 8)] + [win(7, -1, 0), win(7, 0, -1), win(1, 1, 0), win(1, 0, 1), win(2, 1, 0), win(4, 0, 1)]
     allv = torch.cat(parts, dim=-1)
     zero = (allv == 0).all(dim=-1) & ~torch.signbit(allv).any(dim=-1)
+    # ... ZERO also covers the three operands the rows take from the neighbouring vectors: C at z0-1, EXZ and EYZ at z0+vec
+    pz = lambda a: (a == 0) & ~torch.signbit(a)  # noqa: E731
+    c7, c2, c4 = (cls[p][1:Nx - 1, 1:Ny - 1] for p in (7, 2, 4))
+    left = torch.ones_like(zero)
+    left[:, :, 1:] = pz(c7[:, :, vec - 1:Nz - 1:vec])
+    right = torch.ones_like(zero)
+    right[:, :, :-1] = pz(c2[:, :, vec:Nz:vec]) & pz(c4[:, :, vec:Nz:vec])
+    zero = zero & left & right
     bulk = vol[vol > 0].max() if bool((vol > 0).any()) else vol.new_tensor(0.0)     # k_vcg_bulk_value
     one = (allv == bulk).all(dim=-1) & ~zero
     return {"zero": int(zero.sum()), "one": int(one.sum()), "mixed": int((~zero & ~one).sum())}
@@ -244,6 +252,43 @@ def test_compressed_class_access_on_hostile_volumes(dt):
         assert torch.equal(outs[0].view(it)[nz], outs[1].view(it)[nz]), name
         vec = 4 if dt == torch.float32 else 2
         assert census == _torch_census(gres, vol.to(dt), vec), name
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_zero_class_covers_the_operands_taken_from_neighbouring_vectors(dt):
+    """A ZERO vector's rows must be empty, not only its own samples zero: the last cell's u / v rows use EXZ / EYZ at z0+VEC and
+    the first cell's w row C at z0-1, which the march takes from the NEIGHBOURING lanes' registers.  One isolated EXZ sample
+    placed so that (i) it is the first sample of lane 0 of a wave and (ii) every vector of the wave before it has all its own
+    samples zero (rows of 12 / 24 vectors: waves do not end on row boundaries): a classifier that looked at own samples
+    only let that whole wave skip its rows and stored q = 0 for a face whose row is not empty."""
+    require_default_engine("test_zero_class_covers_the_operands_taken_from_neighbouring_vectors")
+    gres = (10, 12, 48)
+    vec = 4 if dt == torch.float32 else 2
+    nzv = gres[2] // vec
+    row, zv = divmod(64, nzv)                  # vector 64 of the plane tile = lane 0 of the second wave
+    x, y, z0 = 5, row + 1, zv * vec
+    sc = scenes.viscosity_scene_3d(gres, seed=7, device=DEV, noise=0.3)
+    sphi = torch.ones_like(sc["sphi"])         # no solids: every interior face is an unknown
+    cell_vol = float(np.prod(np.array(sc["bound_size"]) / np.array(gres)))
+    scale = sc["dt"] / cell_vol / sc["rho"]
+    vol = torch.zeros_like(sc["lvol"])
+    vol[2 * x, 2 * y + 1, 2 * z0] = 0.5        # class EXZ (x even, y odd, z even) at compact index (x, y, z0)
+    outs = []
+    for comp in (True, False):
+        eng = _engine(gres, dt, 1)
+        eng.set_compress(comp)
+        eng.setup(scale, 37.0, sphi, vol)
+        assert eng.apply_kernel() == "march"
+        d, dv = _direction(eng, dict(sc, sphi=sphi), seed=11)
+        vecs = [eng.new_vector()[0] for _ in range(4)]
+        q = vecs[3]
+        q.fill_(3.0)
+        eng.bind(vecs[0], vecs[1], d, vecs[2], q)
+        eng.phase_apply()
+        torch.cuda.synchronize()
+        outs.append(q.clone())
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert float(outs[1].abs().max()) > 0      # (the sample does reach some rows)
 
 
 # ------------------------------------------------------------------ sparse lists of a single-domain solve (round 3) ----
