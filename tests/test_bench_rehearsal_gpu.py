@@ -20,9 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("transport", ["auto", "rccl"])
-def test_bench_two_ranks_on_one_gpu(transport):
-    env = dict(os.environ, MFS_BENCH_SHARED_GPU="1", MFS_P2P_TIMEOUT_MS="5000")
+@pytest.mark.parametrize("transport,extra", [("auto", {}), ("rccl", {}),
+                                             # the production-size flow builds the solve's sparse lists in the slab loops (round 3):
+                                             # forced onto this small grid, so that the cross-checks against the dense phase loop run with them
+                                             ("auto", {"MFS_SPARSE_MIN": "1"})], ids=["auto", "rccl", "auto-sparse-lists"])
+def test_bench_two_ranks_on_one_gpu(transport, extra):
+    env = dict(os.environ, MFS_BENCH_SHARED_GPU="1", MFS_P2P_TIMEOUT_MS="5000", **extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--edge", "48",
            "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--transport", transport]

@@ -356,11 +356,11 @@ def _blob_problem(gres, centre, radius, seed):
 def test_sparse_work_list_and_live_chunks_match_the_dense_loop(dt, monkeypatch):
     """round 3: behind the initial residual a single-domain solve lists the (tile, plane) pairs of the march that compute
     anything and the 32-cell chunks that hold a live unknown; the fused stencil launches and the r update visit only
-    those.  A ball of liquid in a 160 x 96 x 128 box (2 M cells: the size from which the lists are built) -- and then, THROUGH
+    those.  A ball of liquid in a 160 x 96 x 144 box (2.2 M cells: the lists are built from 2^21 cells on) -- and then, THROUGH
     THE SAME ENGINE, a ball elsewhere (the partner buffer of the direction vector still holds the first solve's liquid) --
     against the engine with the lists off: same history to rounding (dot products group differently), same solution."""
     from mfs.pcg import PcgEngine
-    gres = (160, 96, 128)
+    gres = (160, 96, 144)
     outs = {}
     for sparse in ("1", "0"):
         monkeypatch.setenv("MFS_SPARSE", sparse)
@@ -378,6 +378,8 @@ def test_sparse_work_list_and_live_chunks_match_the_dense_loop(dt, monkeypatch):
             assert ok
             # a ball in a box: most lanes of the listed (tile, plane) pairs are dead, so the solve switches its listed launches to
             # the lane-masking form at its first look at the scalar block (and the engine's next solve starts with it)
+            info = eng.sparse_info()
+            assert (info["listed_pairs"] > 0 and info["live_chunks"] > 0) == (sparse == "1"), info
             assert float(eng.scalars[_lib.S_LANE]) == (1.0 if sparse == "1" else 0.0)
             res.append((it, np.asarray(eng.history()), x.clone(), q.clone()))
         outs[sparse] = res

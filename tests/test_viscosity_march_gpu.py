@@ -314,6 +314,8 @@ def test_sparse_lists_match_the_dense_loop(prec, monkeypatch):
             v = [m(sc["vx"]).clone() * (-1.0 if mirrored else 1.0), m(sc["vy"]).clone(), m(sc["vz"]).clone()]
             s.solve(sc["dt"], sc["mu"], sc["rho"], *v, m(sc["sphi"]), m(sc["sv"]), m(sc["lphi"]), m(sc["lvol"]))
             torch.cuda.synchronize()
+            info = s._engine.sparse_info()
+            assert (info["listed_pairs"] > 0 and 0 < info["live_chunks"] < info["chunks"] // 4) == (sparse == "1"), info
             res.append((s.iterations, np.asarray(s.history), [t.clone() for t in v]))
         runs[sparse] = res
     for (it_s, h_s, v_s), (it_d, h_d, v_d) in zip(runs["1"], runs["0"]):
