@@ -59,7 +59,8 @@ def viscosity_mode(rank, world, path, out, dtname, dev):
     np.savez(f"{out}.rank{rank}.npz", vx=vx.cpu().numpy(), vy=vy.cpu().numpy(), vz=vz.cpu().numpy(),
              x_x=c(s.x_x), x_y=c(s.x_y), x_z=c(s.x_z), b_x=c(s.b_x), b_y=c(s.b_y), b_z=c(s.b_z),
              q_x=c(s.q_x), r_x=c(s.r_x), q_y=c(s.q_y), r_y=c(s.r_y),
-             hist=s.history, iters=s.iterations, lo=lo, hi=hi, transport=s.transport)
+             hist=s.history, iters=s.iterations, lo=lo, hi=hi, transport=s.transport,
+             sparse=np.array([v for v in s._engine.sparse_info().values()], dtype=np.int64))
     s.close()
 
 
@@ -419,7 +420,7 @@ def main():
         torch.cuda.synchronize()
         np.savez(f"{out}.rank{rank}.npz", x=x.cpu().numpy().astype(np.float64), hist=eng.history(),
                  iters=st["iterations"], done=int(st["done"]), lo=lo, hi=hi, q=q.cpu().numpy().astype(np.float64),
-                 alloc=win.alloc_kind)
+                 alloc=win.alloc_kind, sparse=np.array([v for v in eng.sparse_info().values()], dtype=np.int64))
         win.close()
     finally:
         dist.destroy_process_group()

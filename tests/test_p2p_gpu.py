@@ -141,6 +141,12 @@ def test_slab_p2p_sparse_lists(name, world, dtname, tmp_path):
             assert int(r["done"]) == 1
             lo, hi = int(r["lo"]), int(r["hi"])
             x[lo + 1:hi - 1] = r["x"][1:-1]
+            live_chunks, chunks, listed, pairs = (int(v) for v in r["sparse"])
+            if sparse == "1":      # the lists WERE built: chunks of the owned planes always, pairs where there is an interior launch
+                assert chunks > 0 and 0 < live_chunks <= chunks, r["sparse"]
+                assert (pairs > 0 and 0 < listed <= pairs) == (hi - lo - 2 > 2), (r["sparse"], lo, hi)
+            else:
+                assert chunks == 0 and pairs == 0, r["sparse"]
         for r in res[1:]:
             np.testing.assert_array_equal(r["hist"], res[0]["hist"])
         out[sparse] = (res[0]["hist"], x, int(res[0]["iters"]))

@@ -52,6 +52,9 @@ def test_slab_viscosity_sparse_lists(name, world, dtname, tmp_path):
 def _check_against_goldens(name, world, dtname, transport, tmp_path, **env):
     g = golden(name)
     res = _run_ranks(name, world, tmp_path, dtname, P2P_TEST_MODE="viscosity", P2P_TEST_TRANSPORT=transport, **env)
+    for r in res:          # the solve's sparse lists: built exactly when forced onto these small grids
+        live_chunks, chunks, listed, pairs = (int(v) for v in r["sparse"])
+        assert (chunks > 0 and live_chunks > 0) == ("MFS_VISC_SPARSE_MIN" in env), (r["sparse"], env)
     assert all(str(r["transport"]) == transport for r in res)
     a = _assemble(g, res)
     for r in res:          # ghost planes of q and r stay exactly 0: the local dot products count owned faces only
