@@ -80,7 +80,10 @@ __device__ __forceinline__ int64_t live_vec(const LiveMap& lm, int64_t k) {
 // unknowns per chunk of a live map: one 128-byte line of fp32 state (8 16-byte vectors).  Much smaller than a z-row of a
 // production grid on purpose -- a liquid body covers PART of a row: with 1024-unknown chunks (four whole rows at Nz = 256) the
 // vector phases of the 256^3 viscosity bench swept 18.7 % of the unknowns for 7 % of liquid, with 128 (half a row) 17.4 %
-constexpr int kLiveChunk = 32;
+#ifndef MFS_LIVE_CHUNK
+#define MFS_LIVE_CHUNK 32        // A/B knob (tools/build_variant.sh chunk64 "-DMFS_LIVE_CHUNK=64")
+#endif
+constexpr int kLiveChunk = MFS_LIVE_CHUNK;
 
 // flags -> ascending list of the indices whose flag is set + their count, once per solve: per-block counts (coalesced
 // reads, ballots), a one-block scan of the block counts, then an ordered per-block compaction.  (A single block walking
