@@ -203,7 +203,10 @@ int mfs_pcg3d_loop_info(mfs_pcg3d* h);
  * initial residual mfs_pcg3d_begin lists the 32-cell chunks holding a live z-vector (row not ZERO, or r, d != 0) and the
  * (tile, plane) pairs of the march holding one; the r update sweeps the listed chunks, the fused stencil launches visit the
  * listed pairs.  Dead vectors keep q = r = d = +0 and x unchanged, which is what the dense loop computes for them; the dot
- * products group differently (rounding).  Slab loops, begin_local / phase callers and the Jacobi loop stay dense.
+ * products group differently (rounding).  The window / collective slab loops (mfs_pcg3d_slab_begin) build the same lists for
+ * their owned planes and their interior launch; begin_local / phase callers and the Jacobi loop stay dense.  Where more than
+ * a quarter of the listed pairs' vectors are dead, the listed launches also mask those vectors' loads and stores lane by lane
+ * (decided per solve on the device, picked up by the host with its first look at the scalar block: slot 13, diagnostics).
  * mfs_pcg3d_sparse_info (host-synchronous): out = {listed chunks, chunks, listed pairs, pairs}; zeros where a list is off. */
 int mfs_pcg3d_set_sparse(mfs_pcg3d* h, int on);
 int mfs_pcg3d_sparse_info(mfs_pcg3d* h, mfs_stream stream, int64_t out[4]);
