@@ -184,6 +184,7 @@ int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream);
 #define MFS_PCG_S_LASTRR 8  /* r.r of the last completed iteration (what the reference keeps in self.delta) */
 #define MFS_PCG_S_ERR 11    /* != 0: the device loop stopped itself: 1 / 2 a peer-to-peer wait of the slab loop timed out,
                                3 d.q == 0, 4 non-finite d.q or r.r */
+#define MFS_PCG_S_LANE 13   /* diagnostics: 1 when the solve's listed launches mask dead vectors lane by lane (mfs_pcg3d_set_sparse) */
 void* mfs_pcg3d_scalars(mfs_pcg3d* h);
 /* performance knobs of the stencil kernel (results are identical for every setting):
  * variant 0 = direct loads, 1 = x-marching in registers, 2 = x-marching + LDS-staged

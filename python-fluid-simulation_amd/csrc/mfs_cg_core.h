@@ -42,7 +42,7 @@ enum { S_DQ = MFS_PCG_S_DQ, S_RR = MFS_PCG_S_RR, S_DELTA = MFS_PCG_S_DELTA, S_TO
        S_DONE = MFS_PCG_S_DONE, S_ITERS = MFS_PCG_S_ITERS, S_ALPHA = MFS_PCG_S_ALPHA, S_BETA = MFS_PCG_S_BETA,
        S_LASTRR = MFS_PCG_S_LASTRR, S_RING = 9 /* 2 slots: delta by iteration parity */,
        S_RZ = 12 /* Jacobi loop: r.z of the latest update */,
-       S_LANE = 13 /* pressure engine: 1 when lane-level masking of the listed launches pays on this solve (pcg_build_live) */,
+       S_LANE = MFS_PCG_S_LANE /* pressure engine: 1 when lane-level masking of the listed launches pays on this solve (pcg_build_live) */,
        S_ERR = MFS_PCG_S_ERR /* != 0: the solve was stopped -- 1 / 2 a peer-to-peer wait timed out (slab loop: all-reduce /
                                 halo plane), 3 d.q == 0 (the reference's ZeroDivisionError, PressureCGSolver3D.py:211),
                                 4 a non-finite d.q or r.r (the reference would spin to max_iter on `nan < tol**2`) */ };
