@@ -753,7 +753,7 @@ k_update_rdx(T* __restrict__ x, T* __restrict__ d, T* __restrict__ r, const T* _
 // end of every non-converged iteration, :220-221)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_d_axpy(T* __restrict__ d, const T* __restrict__ r, int64_t n, const double* __restrict__ scal) {
+k_d_axpy(T* __restrict__ d, const T* __restrict__ r, int64_t n, const double* __restrict__ scal, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   if (scal[S_DONE] != 0.0) return;
   const double beta = scal[S_BETA];
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
@@ -766,14 +766,14 @@ k_d_axpy(T* __restrict__ d, const T* __restrict__ r, int64_t n, const double* __
     } else {
       d[i] = (T)((double)r[i] + beta * (double)d[i]);
     }
-  });
+  }, false, false, lm);      // (a solve's live chunks: r = d = 0 everywhere else)
 }
 
 // x += alpha d with alpha as left in the scalar block (delta / d.q of the last completed iteration): the solution
 // update a loop with the deferred x update still owes when it stops (converged or not)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_x_axpy(T* __restrict__ x, const T* __restrict__ d, int64_t n, const double* __restrict__ scal) {
+k_x_axpy(T* __restrict__ x, const T* __restrict__ d, int64_t n, const double* __restrict__ scal, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   const double alpha = scal[S_ALPHA];
   for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
     if (vec) {
@@ -785,7 +785,7 @@ k_x_axpy(T* __restrict__ x, const T* __restrict__ d, int64_t n, const double* __
     } else {
       x[i] = (T)((double)x[i] + alpha * (double)d[i]);
     }
-  });
+  }, false, false, lm);
 }
 
 // The bookkeeping half of k_update_d on its own (one block): r.r from the partials, convergence

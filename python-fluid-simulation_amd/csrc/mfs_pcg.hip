@@ -977,18 +977,21 @@ static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t s
     const int grid = core_vec_grid(h->c, true);
     const int64_t plane = (int64_t)h->Ny * h->Nz;
     const int64_t off = h->slab_loop ? plane : 0, cnt = h->slab_loop ? plane * (h->Nx - 2) : h->n;   // ghost planes are not ours
-    if (h->dt == MFS_F32) hipLaunchKernelGGL((k_x_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.x + off, (const float*)cur + off, cnt, h->c.scal);
-    else hipLaunchKernelGGL((k_x_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.x + off, (const double*)cur + off, cnt, h->c.scal);
+    // (the solve's live chunks, when they were built over exactly this range: d is 0 everywhere else)
+    const LiveMap lm = (h->c.live.list && off == h->c.live_off && cnt == (h->c.live_cnt < 0 ? h->n : h->c.live_cnt)) ? h->c.live : LiveMap{nullptr, nullptr, 0};
+    if (h->dt == MFS_F32) hipLaunchKernelGGL((k_x_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.x + off, (const float*)cur + off, cnt, h->c.scal, lm);
+    else hipLaunchKernelGGL((k_x_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.x + off, (const double*)cur + off, cnt, h->c.scal, lm);
     MFS_LAUNCH_CHECK();
   }
   if (!converged) {                                           // owed: d_iters = r + beta d_{iters-1}
     const bool vec = ((uintptr_t)cur % 16 == 0) && ((uintptr_t)rsrc % 16 == 0);
     const int grid = core_vec_grid(h->c, vec);
+    const LiveMap lm = (vec && !jac && h->c.live.list && h->c.live_off == 0 && (h->c.live_cnt < 0 || h->c.live_cnt == h->n)) ? h->c.live : LiveMap{nullptr, nullptr, 0};
     if (h->dt == MFS_F32) {
-      if (vec) hipLaunchKernelGGL((k_d_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)rsrc, h->n, h->c.scal);
+      if (vec) hipLaunchKernelGGL((k_d_axpy<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)rsrc, h->n, h->c.scal, lm);
       else hipLaunchKernelGGL((k_d_axpy<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)cur, (const float*)rsrc, h->n, h->c.scal);
     } else {
-      if (vec) hipLaunchKernelGGL((k_d_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)rsrc, h->n, h->c.scal);
+      if (vec) hipLaunchKernelGGL((k_d_axpy<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)rsrc, h->n, h->c.scal, lm);
       else hipLaunchKernelGGL((k_d_axpy<double, 1>), dim3(grid), dim3(kBlock), 0, st, (double*)cur, (const double*)rsrc, h->n, h->c.scal);
     }
     MFS_LAUNCH_CHECK();
