@@ -769,6 +769,16 @@ k_d_axpy(T* __restrict__ d, const T* __restrict__ r, int64_t n, const double* __
   }, false, false, lm);      // (a solve's live chunks: r = d = 0 everywhere else)
 }
 
+// dst = src over a solve's live chunks (the direction vector brought home from the engine's partner buffer: both hold 0
+// everywhere else)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_copy_live(T* __restrict__ dst, const T* __restrict__ src, int64_t n, LiveMap lm) {
+  for_each_vec<T, VEC>(n, [&](int64_t i, bool vec) {
+    if (vec) vstore<T, VEC>(dst + i, vload<T, VEC>(src + i)); else dst[i] = src[i];
+  }, false, false, lm);
+}
+
 // x += alpha d with alpha as left in the scalar block (delta / d.q of the last completed iteration): the solution
 // update a loop with the deferred x update still owes when it stops (converged or not)
 template <typename T, int VEC>

@@ -996,7 +996,18 @@ static int pcg_home_d(mfs_pcg3d* h, int64_t iters, bool converged, hipStream_t s
     }
     MFS_LAUNCH_CHECK();
   }
-  if (cur != h->c.d) MFS_HIP_TRY(hipMemcpyAsync(h->c.d, cur, (size_t)h->n * h->c.elt, hipMemcpyDeviceToDevice, st));
+  if (cur != h->c.d) {
+    const bool whole = h->c.live.list && !jac && h->c.live_off == 0 && (h->c.live_cnt < 0 || h->c.live_cnt == h->n) && core_vec_ok(h->c) &&
+                       ((uintptr_t)cur % 16 == 0);
+    if (whole) {      // (both buffers hold 0 outside the solve's live chunks)
+      const int grid = core_vec_grid(h->c, true);
+      if (h->dt == MFS_F32) hipLaunchKernelGGL((k_copy_live<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)h->c.d, (const float*)cur, h->n, h->c.live);
+      else hipLaunchKernelGGL((k_copy_live<double, 2>), dim3(grid), dim3(kBlock), 0, st, (double*)h->c.d, (const double*)cur, h->n, h->c.live);
+      MFS_LAUNCH_CHECK();
+    } else {
+      MFS_HIP_TRY(hipMemcpyAsync(h->c.d, cur, (size_t)h->n * h->c.elt, hipMemcpyDeviceToDevice, st));
+    }
+  }
   return MFS_OK;
 }
 
