@@ -205,7 +205,8 @@ int mfs_pcg3d_loop_info(mfs_pcg3d* h);
  * (tile, plane) pairs of the march holding one; the r update sweeps the listed chunks, the fused stencil launches visit the
  * listed pairs.  Dead vectors keep q = r = d = +0 and x unchanged, which is what the dense loop computes for them; the dot
  * products group differently (rounding).  The window / collective slab loops (mfs_pcg3d_slab_begin) build the same lists for
- * their owned planes and their interior launch; begin_local / phase callers and the Jacobi loop stay dense.  Where more than
+ * their owned planes and their interior launch, and so does the fused single-domain Jacobi loop (z = r / diag is 0 wherever r
+ * is); begin_local / phase callers, the slab and the three-launch Jacobi loops stay dense.  Where more than
  * a quarter of the listed pairs' vectors are dead, the listed launches also mask those vectors' loads and stores lane by lane
  * (decided per solve on the device, picked up by the host with its first look at the scalar block: slot 13, diagnostics).
  * mfs_pcg3d_sparse_info (host-synchronous): out = {listed chunks, chunks, listed pairs, pairs}; zeros where a list is off. */
@@ -361,7 +362,8 @@ int mfs_vcg3d_class_census(mfs_vcg3d* h, int64_t counts_host[3], mfs_stream stre
  * r and d / x updates sweep the 32-unknown chunks holding a face whose row is not empty (or r, d != 0), and -- with the
  * compressed class access -- the march launches of mfs_vcg3d_iterate visit only the (tile, plane) pairs that are not all air
  * (their q = +0 was stored by the solve's initial q = A x; nothing else writes it).  Values as in the dense loop; the dot
- * products group differently.  Slab loops, phase callers, the fused and the Jacobi loop stay dense.
+ * products group differently.  The window slab loop and the single-domain Jacobi loop take the lists too; phase callers, the
+ * opt-in fused loop and the slab Jacobi loop stay dense.
  * mfs_vcg3d_sparse_info (host-synchronous): out = {listed chunks, chunks, listed pairs, pairs} of the solve begun last. */
 int mfs_vcg3d_set_sparse(mfs_vcg3d* h, int on);
 int mfs_vcg3d_sparse_info(mfs_vcg3d* h, mfs_stream stream, int64_t out[4]);

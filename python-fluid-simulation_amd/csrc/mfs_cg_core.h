@@ -1001,7 +1001,7 @@ k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
                 const T* __restrict__ diag, T* __restrict__ z, int64_t n, double* __restrict__ scal,
                 double* __restrict__ part_rr, double* __restrict__ part_rz, int par, const double* __restrict__ part_dq,
                 int npart, const unsigned char* __restrict__ cls, double* __restrict__ hist, int64_t hist_cap,
-                unsigned* __restrict__ ticket, JacSlab sl) {
+                unsigned* __restrict__ ticket, JacSlab sl, LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   const double dn = scal[S_DONE];
   const double delta = scal[S_RING + par];
   // d.q: folded from the stencil launch's partials (one GPU) or the all-reduced scalar (slab loop: npart == 0)
@@ -1050,7 +1050,7 @@ k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
       arr += (double)rn * (double)rn;
       arz += (double)rn * zz;
     }
-  });
+  }, false, false, lm);      // (a solve's live chunks: r = z = d = 0 everywhere else)
   const double t1 = block_sum<kBlock>(arr);
   const double t2 = block_sum<kBlock>(arz);
   double rr, rz;
@@ -1073,7 +1073,8 @@ k_jac_update_rz(T* __restrict__ x, const T* __restrict__ d, T* __restrict__ r, c
 // behind a converged (or failed) iteration find S_ITERS != their own it + 1 and do nothing.
 template <typename T, int VEC, bool NTX>
 __global__ void __launch_bounds__(kBlock)
-k_jac_dx(T* __restrict__ x, T* __restrict__ d, const T* __restrict__ z, int64_t n, const double* __restrict__ scal, double it) {
+k_jac_dx(T* __restrict__ x, T* __restrict__ d, const T* __restrict__ z, int64_t n, const double* __restrict__ scal, double it,
+         LiveMap lm = LiveMap{nullptr, nullptr, 0}) {
   if (scal[S_ITERS] != it + 1.0 || scal[S_ERR] != 0.0) return;
   const bool conv = scal[S_DONE] != 0.0;
   const double alpha = scal[S_ALPHA], beta = conv ? 0.0 : scal[S_BETA];
@@ -1094,7 +1095,7 @@ k_jac_dx(T* __restrict__ x, T* __restrict__ d, const T* __restrict__ z, int64_t 
       if (conv) return;
       d[i] = (T)((double)z[i] + beta * (double)d[i]);
     }
-  });
+  }, false, false, lm);
 }
 
 // ------------------------------------------------------------- host side ----

@@ -578,6 +578,7 @@ int mfs_pcg3d_begin_finish(mfs_pcg3d* h, mfs_stream stream) {
 }  // extern "C"
 
 static bool native_fuse_ok(const mfs_pcg3d* h);
+static bool jac_fuse_ok(const mfs_pcg3d* h);
 
 // ---- live chunks of the cell vectors (mfs_cg_core.h LiveMap): a z-vector is DEAD when every computed cell of it is a
 // ZERO row (not fluid: k_pcg_classify) and r = d = 0 there at the start of the loop -- q, r and d then stay exactly 0 for the
@@ -625,7 +626,9 @@ static int pcg_build_live(mfs_pcg3d* h, hipStream_t st, bool slab = false) {
   h->c.live = LiveMap{nullptr, nullptr, 0};
   h->c.live_off = 0; h->c.live_cnt = h->n;
   h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
-  if (!h->sparse_vec || !h->compress || !h->vec_ok || !core_vec_ok(h->c) || h->n < h->sparse_min || h->jacobi) return MFS_OK;
+  // (the opt-in Jacobi loop: its fused single-domain form only -- z = r / diag is 0 wherever r is, so a dead vector stays dead)
+  if (!h->sparse_vec || !h->compress || !h->vec_ok || !core_vec_ok(h->c) || h->n < h->sparse_min) return MFS_OK;
+  if (h->jacobi && (slab || !jac_fuse_ok(h))) return MFS_OK;
   const int vec = h->dt == MFS_F32 ? 4 : 2;
   const int64_t plane_elems = (int64_t)h->Ny * h->Nz;
   if (slab && h->Nx < 3) return MFS_OK;
@@ -644,7 +647,7 @@ static int pcg_build_live(mfs_pcg3d* h, hipStream_t st, bool slab = false) {
   const int64_t gr[3] = {h->Nx, h->Ny, h->Nz};
   const int64_t npairs = (int64_t)tiles * np;
   const bool skip = h->Nx >= 3 && h->Ny >= 3 && np > 0 && npairs > 0 && npairs <= skip_pairs(gr, h->dt) && npairs < 0x7fffffff &&
-                    (slab || native_fuse_ok(h));
+                    (slab || native_fuse_ok(h) || jac_fuse_ok(h));
   int* tflags = h->skip_ws;
   int* items = tflags + npairs;
   int* runrem = items + npairs;
@@ -670,6 +673,9 @@ static int pcg_build_live(mfs_pcg3d* h, hipStream_t st, bool slab = false) {
     MFS_LAUNCH_CHECK();
     // the partner buffer of the direction vector must be 0 wherever the loop never writes it (a previous solve's liquid)
     MFS_HIP_TRY(hipMemsetAsync(h->d2, 0, (size_t)h->n * h->c.elt, st));
+    // ... and so must the Jacobi loop's stored z (the r / z update sweeps the live chunks only; the stencil launch reads z of
+    // every vector of a listed pair)
+    if (h->jacobi) MFS_HIP_TRY(hipMemsetAsync(h->zb, 0, (size_t)h->n * h->c.elt, st));
     h->skip_items = items; h->skip_runrem = runrem; h->skip_count = scount;
     h->skip_xb = xb; h->skip_xe = xe;
   }
@@ -723,7 +729,8 @@ int mfs_pcg3d_begin(mfs_pcg3d* h, double tol, mfs_stream stream) {
     h->slab_loop = false;
     h->c.live = LiveMap{nullptr, nullptr, 0};
     h->skip_items = nullptr; h->skip_runrem = nullptr; h->skip_count = nullptr;
-    return jac_begin(h, tol, (hipStream_t)stream);
+    if (int e = jac_begin(h, tol, (hipStream_t)stream)) return e;
+    return pcg_build_live(h, (hipStream_t)stream);
   }
   if (int e = mfs_pcg3d_begin_local(h, tol, stream)) return e;
   if (int e = mfs_pcg3d_begin_finish(h, stream)) return e;
@@ -773,14 +780,15 @@ static int jac_iteration_fused(mfs_pcg3d* h, hipStream_t st) {
   const int g = core_vec_grid(h->c, true);
   const int par = (int)(j & 1);
   const unsigned char* cls = h->compress != 0 ? h->cls : nullptr;      // class bytes are valid whenever the march uses them
+  const LiveMap lm = (h->c.live.list && h->c.live_off == 0 && (h->c.live_cnt < 0 || h->c.live_cnt == h->n)) ? h->c.live : LiveMap{nullptr, nullptr, 0};
   if (xdef)
     hipLaunchKernelGGL((k_jac_update_rz<T, VEC, false>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
                        (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
-                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets, JacSlab{});
+                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets, JacSlab{}, lm);
   else
     hipLaunchKernelGGL((k_jac_update_rz<T, VEC, true>), dim3(g), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)d_cur, (T*)h->c.r,
                        (const T*)h->c.q, (const T*)h->diag, (T*)h->zb, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
-                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets, JacSlab{});
+                       h->c.part_dq, h->c.n_part_dq, cls, h->c.hist, kHistCap, h->c.tickets, JacSlab{}, lm);
   MFS_LAUNCH_CHECK();
   h->c.n_part_rr = g;
   if (xdef) h->x_owed = true;

@@ -1847,6 +1847,11 @@ int mfs_vcg3d_begin(mfs_vcg3d* h, double tol, mfs_stream stream) {
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kBlock), 0, st, h->part_rz, g2, h->c.scal, (int)S_RZ, 0);
     hipLaunchKernelGGL(k_jac_begin_finish, dim3(1), dim3(64), 0, st, h->c.scal, h->c.hist);
     MFS_LAUNCH_CHECK();
+    // the solve's sparse lists for the opt-in Jacobi loop too (z = r / diag is 0 wherever r is: a dead face stays dead); the
+    // stored z (the z form keeps it in the fused loop's partner buffer) must then be 0 outside the live chunks
+    if (h->p2p || h->skip_top_x) return MFS_OK;
+    if (int e = vcg_build_live(h, st)) return e;
+    if (h->c.live.list) MFS_HIP_TRY(hipMemsetAsync(h->d2, 0, (size_t)h->n * h->c.elt, st));
     return MFS_OK;
   }
   if (int e = core_begin_post(h->c, st)) return e;                // :577-585
@@ -2004,12 +2009,12 @@ static int vcg_jac_iteration_z(mfs_vcg3d* h, hipStream_t st) {
   const int par = (int)(h->c.iter_enq & 1);
   hipLaunchKernelGGL((k_jac_update_rz<T, VEC, false>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (const T*)h->c.d, (T*)h->c.r,
                      (const T*)h->c.q, (const T*)h->diag, (T*)h->d2, h->n, h->c.scal, h->c.part_rr, h->part_rz, par,
-                     h->c.part_dq, h->c.n_part_dq, (const unsigned char*)nullptr, h->c.hist, kHistCap, h->c.tickets, JacSlab{});
+                     h->c.part_dq, h->c.n_part_dq, (const unsigned char*)nullptr, h->c.hist, kHistCap, h->c.tickets, JacSlab{}, h->c.live);
   const bool ntx = 5.0 * (double)h->n * h->c.elt > 200e6;
   if (ntx) hipLaunchKernelGGL((k_jac_dx<T, VEC, true>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (T*)h->c.d, (const T*)h->d2, h->n,
-                              h->c.scal, (double)h->c.iter_enq);
+                              h->c.scal, (double)h->c.iter_enq, h->c.live);
   else hipLaunchKernelGGL((k_jac_dx<T, VEC, false>), dim3(grid), dim3(kBlock), 0, st, (T*)h->c.x, (T*)h->c.d, (const T*)h->d2, h->n,
-                          h->c.scal, (double)h->c.iter_enq);
+                          h->c.scal, (double)h->c.iter_enq, h->c.live);
   MFS_LAUNCH_CHECK();
   h->c.n_part_rr = grid;
   ++h->c.iter_enq;
@@ -2085,6 +2090,8 @@ int mfs_vcg3d_iterate(mfs_vcg3d* h, int64_t n, mfs_stream stream) {
     // consumers fold the partial sums themselves (MFS_VISC_JACOBI_Z = 0 / 1 overrides)
     const int zk = env_int("MFS_VISC_JACOBI_Z", -1);
     const bool zform = zk < 0 ? (5.0 * (double)h->n * h->c.elt > 100e6) : (zk != 0);
+    VcgListScope list(h, st);      // (single-domain solves with lists: the march visits the busy pairs only)
+    if (list.err) return list.err;
     for (int64_t i = 0; i < n; ++i) {
       int e;
       if (vec && zform) e = h->dt == MFS_F32 ? vcg_jac_iteration_z<float, 4>(h, st) : vcg_jac_iteration_z<double, 2>(h, st);

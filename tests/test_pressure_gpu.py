@@ -393,6 +393,42 @@ def test_sparse_work_list_and_live_chunks_match_the_dense_loop(dt, monkeypatch):
         assert torch.equal(x_s[air], x_d[air])         # nothing leaks into the air
 
 
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_sparse_lists_in_the_fused_jacobi_loop(dt):
+    """the opt-in Jacobi loop's fused single-domain form takes the solve's lists as well (z = r / diag is 0 wherever r is: a dead
+    vector stays dead; the stored z and the partner d buffer are cleared when the lists are built).  Ball-in-a-box problem at
+    2.2 M cells, two solves through one engine (the ball moves), against the same loop with the lists off: same history to
+    rounding, same solution, nothing leaks into the air."""
+    from mfs.pcg import PcgEngine
+    gres = (160, 96, 144)
+    outs = {}
+    for sparse in (True, False):
+        eng = PcgEngine(gres, dt, DEV)
+        eng.set_jacobi(True)
+        eng.set_sparse(sparse)
+        res = []
+        for centre, radius, seed in (((50.0, 40.0, 60.0), 22.0, 1), ((110.0, 60.0, 70.0), 18.0, 2)):
+            lphi, wx, wy, wz, b = _blob_problem(gres, centre, radius, seed)
+            eng.setup(lphi.to(dt), wx.to(dt), wy.to(dt), wz.to(dt))
+            x, d, r, q = (torch.zeros(gres, dtype=dt, device=DEV) for _ in range(4))
+            q[1:-1, 1:-1, 1:-1] = 5.0
+            eng.bind(b.to(dt), x, d, r, q)
+            ok, it = eng.solve(1e-6 if dt == torch.float64 else 1e-3, 4000, 16)
+            torch.cuda.synchronize()
+            assert ok and eng.loop_info()["jacobi"] and eng.loop_info()["fused_direction_update"]
+            info = eng.sparse_info()
+            assert (info["listed_pairs"] > 0 and info["live_chunks"] > 0) == sparse, info
+            res.append((it, np.asarray(eng.history()), x.clone()))
+        outs[sparse] = res
+    for (it_s, h_s, x_s), (it_d, h_d, x_d) in zip(outs[True], outs[False]):
+        assert abs(it_s - it_d) <= 1, (it_s, it_d)
+        n = min(len(h_s), len(h_d), 41)
+        np.testing.assert_allclose(h_s[:n], h_d[:n], rtol=1e-10 if dt == torch.float64 else 1e-4)
+        assert float((x_s - x_d).abs().max()) <= (1e-8 if dt == torch.float64 else 1e-3) * float(x_d.abs().max())
+        air = x_d == 0
+        assert torch.equal(x_s[air], x_d[air])
+
+
 def test_sparse_lists_are_off_for_small_grids_and_on_from_two_million_cells():
     from mfs.pcg import PcgEngine
     for gres, on in (((24, 20, 16), False), ((160, 96, 144), True)):

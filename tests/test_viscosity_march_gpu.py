@@ -326,3 +326,36 @@ def test_sparse_lists_match_the_dense_loop(prec, monkeypatch):
             assert float((a - b).abs().max()) <= (1e-8 if prec == "fp64" else 1e-3) * float(b.abs().max())
     # the mirrored solve is the mirror image of the first one (same operator, mirrored): its iteration count agrees
     assert abs(runs["1"][0][0] - runs["1"][1][0]) <= 2
+
+
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_sparse_lists_in_the_jacobi_loop(prec, monkeypatch):
+    """the opt-in Jacobi loop takes the solve's lists as well (z = r / diag is 0 wherever r is; the stored z is cleared when the
+    lists are built): 96^3 buckling-like scene, then the scene mirrored in x through the same solver, against MFS_VISC_SPARSE=0 --
+    same iteration count (+-1), same history to rounding, same velocities."""
+    require_default_engine("test_sparse_lists_in_the_jacobi_loop")
+    import solver.ViscosityCGSolver3D as V
+    gres = (96, 96, 96)
+    sc = scenes.viscosity_scene_3d(gres, seed=5, device=DEV)
+    flip = lambda t: t.flip(0).contiguous()  # noqa: E731
+    runs = {}
+    for sparse in ("1", "0"):
+        monkeypatch.setenv("MFS_VISC_SPARSE", sparse)
+        s = V.ViscosityCGSolver3D(gres, sc["bound_size"], precision=prec, device=DEV, jacobi=True)
+        res = []
+        for mirrored in (False, True):
+            m = flip if mirrored else (lambda t: t)
+            v = [m(sc["vx"]).clone() * (-1.0 if mirrored else 1.0), m(sc["vy"]).clone(), m(sc["vz"]).clone()]
+            s.solve(sc["dt"], sc["mu"], sc["rho"], *v, m(sc["sphi"]), m(sc["sv"]), m(sc["lphi"]), m(sc["lvol"]))
+            torch.cuda.synchronize()
+            assert s._engine.loop_info()["jacobi"]
+            info = s._engine.sparse_info()
+            assert (info["listed_pairs"] > 0 and 0 < info["live_chunks"] < info["chunks"] // 4) == (sparse == "1"), info
+            res.append((s.iterations, np.asarray(s.history), [t.clone() for t in v]))
+        runs[sparse] = res
+    for (it_s, h_s, v_s), (it_d, h_d, v_d) in zip(runs["1"], runs["0"]):
+        assert abs(it_s - it_d) <= 1, (it_s, it_d)
+        n = min(len(h_s), len(h_d), 41)
+        np.testing.assert_allclose(h_s[:n], h_d[:n], rtol=1e-9 if prec == "fp64" else 2e-4)
+        for a, b in zip(v_s, v_d):
+            assert float((a - b).abs().max()) <= (1e-8 if prec == "fp64" else 1e-3) * float(b.abs().max())
