@@ -14,7 +14,7 @@ dev = "cuda:0"
 bad = 0
 
 
-def pressure_case(k):
+def pressure_case(k, jacobi=False):
     global bad
     gres = [(160, 96, 144), (130, 128, 128), (96, 160, 160), (258, 96, 96)][k % 4]
     dt = torch.float64 if k % 2 == 0 else torch.float32
@@ -37,6 +37,8 @@ def pressure_case(k):
     for sparse in (True, False):
         eng = PcgEngine(gres, dt, dev)
         eng.set_sparse(sparse)
+        if jacobi:
+            eng.set_jacobi(True)
         eng.setup(lphi.to(dt), wx.to(dt), wy.to(dt), wz.to(dt))
         x, d, r, q = (torch.zeros(gres, dtype=dt, device=dev) for _ in range(4))
         eng.bind(b.to(dt), x, d, r, q)
@@ -53,7 +55,7 @@ def pressure_case(k):
     ok = c1 and c0 and hdev < (1e-9 if dt == torch.float64 else 1e-4) and xdev < 1e-4 and abs(it1 - it0) <= max(3, it0 // 10) and \
         info["listed_pairs"] > 0 and torch.equal(x1[x0 == 0], x0[x0 == 0])
     bad += not ok
-    print(f"pressure {k:2d} {str(gres):16s} {str(dt)[6:]:8s} fluid {float((lphi < 0).double().mean()):.3f} pairs {info['listed_pairs']}/{info['pairs']} "
+    print(f"pressure{' jacobi' if jacobi else ''} {k:2d} {str(gres):16s} {str(dt)[6:]:8s} fluid {float((lphi < 0).double().mean()):.3f} pairs {info['listed_pairs']}/{info['pairs']} "
           f"chunks {info['live_chunks']}/{info['chunks']} lane-mask {int(lane)} | iterations {it1} / {it0}: history dev (first {n}) {hdev:.1e} "
           f"converged x dev {xdev:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
 
@@ -101,6 +103,8 @@ def viscosity_case(k):
 
 for k in range(cases):
     pressure_case(k)
+for k in range(cases):
+    pressure_case(k, jacobi=True)      # the opt-in Jacobi loop's fused form takes the lists too
 for k in range(cases):
     viscosity_case(k)
 print("VERDICT:", "all cases agree" if bad == 0 else f"{bad} MISMATCHES")
