@@ -1291,6 +1291,9 @@ static inline int core_update_d(CgCore& c, bool fold, hipStream_t st, bool xupd 
 }
 
 // can the merged vector phases serve this engine?  (aligned vectors, everything in kRdxW workgroups' registers)
+// (Not for solves with live chunks: holding the LIVE vectors of a 128^3 viscosity solve in this kernel -- tried in round 3, sized
+// from the count the host's last look brought back -- was slower than the two streaming kernels on the chunk list, 29.1 vs
+// 24.1 ms per 128^3 solve: 128 workgroups are half the chip.  Those grids are larger than the limit below anyway.)
 static inline bool core_rdx_ok(const CgCore& c) {
   if (!c.rdx || !c.x || !core_vec_ok(c)) return false;
   const int64_t per = c.dt == MFS_F32 ? 4 : 2;
@@ -1314,7 +1317,9 @@ static inline int core_update_rdx(CgCore& c, hipStream_t st) {
 #define MFS_RDX_KV(TT, VV) \
   do { if (need <= 1) MFS_RDX_GO(TT, VV, 1); else if (need <= 2) MFS_RDX_GO(TT, VV, 2); else if (need <= 4) MFS_RDX_GO(TT, VV, 4); \
        else if (need <= 6) MFS_RDX_GO(TT, VV, 6); else MFS_RDX_GO(TT, VV, 8); } while (0)
-  if (c.dt == MFS_F32) MFS_RDX_KV(float, 4); else MFS_RDX_KV(double, 2);
+  // (the fp64 one-vector form compiles to 256 VGPRs with spills -- a compiler artefact of that instantiation: two vectors instead)
+  const int need_d = need < 2 ? 2 : need;
+  if (c.dt == MFS_F32) { MFS_RDX_KV(float, 4); } else { const int need = need_d; MFS_RDX_KV(double, 2); }
 #undef MFS_RDX_KV
 #undef MFS_RDX_GO
   MFS_LAUNCH_CHECK();
