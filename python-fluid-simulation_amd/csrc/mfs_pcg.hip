@@ -357,7 +357,9 @@ int mfs_pcg3d_create(mfs_pcg3d** out, const int64_t gres[3], int dt, void* works
   h->xchunk = env_int("MFS_APPLY_XCHUNK", 0);
   h->nt = env_int("MFS_APPLY_NT", -1);
   h->nt_auto = env_int("MFS_APPLY_NT_AUTO", 7);
-  h->bpc = env_int("MFS_APPLY_BLOCKS_PER_CU", 3);
+  // workgroups per CU the march's work is cut into: 2 since round 3 (same-process A/B on the bench workload, tools/pd_probe.py,
+  // 2 vs 3: timed loop 87.3 vs 89.7 us, dense plain apply 73.5 vs 83.8, fp64 timed loop 170.8 vs 172.8; 1 and 4 lose everywhere)
+  h->bpc = env_int("MFS_APPLY_BLOCKS_PER_CU", 2);
   h->grid_apply = std::min(kMaxPartials, h->cus * 8);
   h->is_setup = false;
   h->p2p = nullptr;

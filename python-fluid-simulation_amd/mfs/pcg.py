@@ -42,7 +42,7 @@ class PcgEngine:
             except Exception:
                 pass
 
-    def tune(self, variant=2, xchunk=0, blocks_per_cu=3, nontemporal=-1):
+    def tune(self, variant=2, xchunk=0, blocks_per_cu=2, nontemporal=-1):
         _lib.check(self.lib.mfs_pcg3d_tune(self.h, int(variant), int(xchunk), int(blocks_per_cu), int(nontemporal)),
                    "mfs_pcg3d_tune")
 
